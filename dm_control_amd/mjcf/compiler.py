@@ -1,0 +1,1074 @@
+"""MJCF-subset compiler: XML string (+ assets) -> `Model`.
+
+Replaces the `mj_loadXML` call the reference makes inside libmujoco
+(/root/reference/dm_control/mujoco/wrapper/core.py:312-376).  MuJoCo's compiler
+is not part of the reference tree; the semantics implemented here are restated
+from MuJoCo's public MJCF documentation ("compile-time
+quirks") and cover what the Control Suite models on the hot path use:
+
+  <include>, nested <default class>/childclass, <compiler angle eulerseq
+  settotalmass inertiafromgeom>, <option timestep gravity integrator cone solver
+  iterations tolerance impratio> + <flag>, bodies with pos/quat/euler/axisangle/
+  xyaxes/zaxis, <inertial>, joints free/ball/slide/hinge (+<freejoint>), geoms
+  plane/sphere/capsule/cylinder/ellipsoid/box with size/fromto/mass/density,
+  motor/position/velocity/general actuators on joints, sensors (layout for all
+  kinds; values for the kinds the suite tasks read), <contact><exclude>.
+
+Anything that would change the physics but is not implemented (tendons, meshes,
+equality constraints, frictionloss, ...) raises `CompileError` instead of being
+silently dropped.
+
+Derived constants that libmujoco fills in `mj_setConst` (`dof_invweight0`,
+`body_invweight0`, `body_subtreemass`, `stat.meaninertia`) are computed in
+`_set_const` with an independent numpy formulation (body-Jacobian sum rather
+than CRBA), which doubles as a cross-check on the native mass-matrix code.
+"""
+
+import math
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from dm_control_amd.mjcf import model as mdl
+
+
+class CompileError(ValueError):
+  """Raised for malformed or unsupported MJCF (cf. `wrapper.Error`)."""
+
+
+_ACTUATOR_TAGS = ('motor', 'position', 'velocity', 'general')
+_UNSUPPORTED_SECTIONS = ('tendon', 'equality', 'keyframe', 'custom')
+_IGNORED_SECTIONS = ('asset', 'visual', 'statistic', 'size')
+_IGNORED_BODY_CHILDREN = ('light', 'camera')
+
+
+# ----------------------------------------------------------------------------
+# small math helpers (quaternions are (w, x, y, z))
+# ----------------------------------------------------------------------------
+def _normalize(v):
+  v = np.asarray(v, dtype=np.float64)
+  n = np.linalg.norm(v)
+  if n < mdl.MJ_MINVAL:
+    raise CompileError('zero-length vector where a direction is required')
+  return v / n
+
+
+def quat_mul(a, b):
+  aw, ax, ay, az = a
+  bw, bx, by, bz = b
+  return np.array([
+      aw*bw - ax*bx - ay*by - az*bz,
+      aw*bx + ax*bw + ay*bz - az*by,
+      aw*by - ax*bz + ay*bw + az*bx,
+      aw*bz + ax*by - ay*bx + az*bw])
+
+
+def quat_to_mat(q):
+  w, x, y, z = q
+  return np.array([
+      [w*w + x*x - y*y - z*z, 2*(x*y - w*z), 2*(x*z + w*y)],
+      [2*(x*y + w*z), w*w - x*x + y*y - z*z, 2*(y*z - w*x)],
+      [2*(x*z - w*y), 2*(y*z + w*x), w*w - x*x - y*y + z*z]])
+
+
+def mat_to_quat(m):
+  """Rotation matrix -> unit quaternion with w >= 0."""
+  t = np.trace(m)
+  if t > 0:
+    s = math.sqrt(t + 1.0) * 2
+    q = np.array([0.25*s, (m[2, 1]-m[1, 2])/s, (m[0, 2]-m[2, 0])/s,
+                  (m[1, 0]-m[0, 1])/s])
+  elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+    s = math.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+    q = np.array([(m[2, 1]-m[1, 2])/s, 0.25*s, (m[0, 1]+m[1, 0])/s,
+                  (m[0, 2]+m[2, 0])/s])
+  elif m[1, 1] > m[2, 2]:
+    s = math.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+    q = np.array([(m[0, 2]-m[2, 0])/s, (m[0, 1]+m[1, 0])/s, 0.25*s,
+                  (m[1, 2]+m[2, 1])/s])
+  else:
+    s = math.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+    q = np.array([(m[1, 0]-m[0, 1])/s, (m[0, 2]+m[2, 0])/s,
+                  (m[1, 2]+m[2, 1])/s, 0.25*s])
+  q /= np.linalg.norm(q)
+  return q if q[0] >= 0 else -q
+
+
+def axis_angle_to_quat(axis, angle):
+  axis = _normalize(axis)
+  return np.concatenate([[math.cos(angle/2)], axis*math.sin(angle/2)])
+
+
+def z_to_quat(vec):
+  """Minimal rotation taking +z onto `vec` (geom `zaxis` / `fromto`)."""
+  vec = _normalize(vec)
+  axis = np.cross([0.0, 0.0, 1.0], vec)
+  s = np.linalg.norm(axis)
+  if s < 1e-10:
+    axis = np.array([1.0, 0.0, 0.0])
+  else:
+    axis /= s
+  ang = math.atan2(s, vec[2])
+  return np.concatenate([[math.cos(ang/2)], axis*math.sin(ang/2)])
+
+
+def _floats(text, n=None, what='attribute'):
+  vals = [float(t) for t in text.split()]
+  if n is not None and len(vals) != n:
+    raise CompileError('%s expects %d numbers, got %r' % (what, n, text))
+  return vals
+
+
+def _bool(text, what):
+  if text not in ('true', 'false'):
+    raise CompileError('%s must be "true" or "false", got %r' % (what, text))
+  return text == 'true'
+
+
+# ----------------------------------------------------------------------------
+# XML preprocessing
+# ----------------------------------------------------------------------------
+def _expand_includes(elem, assets, depth=0):
+  if depth > 16:
+    raise CompileError('<include> nesting too deep')
+  out = []
+  for child in list(elem):
+    if child.tag == 'include':
+      fname = child.get('file')
+      data = None
+      if assets:
+        for key in (fname, fname.lstrip('./')):
+          if key in assets:
+            data = assets[key]
+            break
+        if data is None:
+          base = fname.split('/')[-1]
+          for key, val in assets.items():
+            if key.split('/')[-1] == base:
+              data = val
+              break
+      if data is None:
+        raise CompileError('Error opening file %r' % fname)
+      if isinstance(data, bytes):
+        data = data.decode('utf-8')
+      sub = ET.fromstring(data)
+      _expand_includes(sub, assets, depth + 1)
+      out.extend(list(sub))
+    else:
+      _expand_includes(child, assets, depth)
+      out.append(child)
+  elem[:] = out
+
+
+class _Defaults:
+  """Default-class tree: class name -> tag -> attribute dict."""
+
+  def __init__(self):
+    self.classes = {'main': {}}
+
+  def add(self, elem, cls, parent):
+    if cls not in self.classes:
+      self.classes[cls] = {t: dict(a)
+                           for t, a in self.classes[parent].items()}
+    table = self.classes[cls]
+    for child in elem:
+      if child.tag == 'default':
+        sub = child.get('class')
+        if sub is None:
+          raise CompileError('nested <default> needs a class name')
+        self.add(child, sub, cls)
+      else:
+        tag = '_actuator' if child.tag in _ACTUATOR_TAGS else child.tag
+        table.setdefault(tag, {}).update(child.attrib)
+
+  def resolve(self, elem, active_class):
+    cls = elem.get('class') or active_class or 'main'
+    if cls not in self.classes:
+      raise CompileError('unknown default class %r' % cls)
+    tag = '_actuator' if elem.tag in _ACTUATOR_TAGS else elem.tag
+    attrs = dict(self.classes[cls].get(tag, {}))
+    attrs.update(elem.attrib)
+    return attrs
+
+
+# ----------------------------------------------------------------------------
+# geom mass properties
+# ----------------------------------------------------------------------------
+def _geom_volume(gtype, size):
+  if gtype == mdl.GEOM_SPHERE:
+    return 4.0/3.0*math.pi*size[0]**3
+  if gtype == mdl.GEOM_CAPSULE:
+    h = 2*size[1]
+    return math.pi*(size[0]**2*h + 4.0/3.0*size[0]**3)
+  if gtype == mdl.GEOM_CYLINDER:
+    return math.pi*size[0]**2*2*size[1]
+  if gtype == mdl.GEOM_ELLIPSOID:
+    return 4.0/3.0*math.pi*size[0]*size[1]*size[2]
+  if gtype == mdl.GEOM_BOX:
+    return 8.0*size[0]*size[1]*size[2]
+  return 0.0
+
+
+def _geom_inertia(gtype, size, mass):
+  """Principal inertia in the geom frame."""
+  if gtype == mdl.GEOM_SPHERE:
+    i = 2.0*mass*size[0]**2/5.0
+    return np.array([i, i, i])
+  if gtype == mdl.GEOM_CAPSULE:
+    r, height = size[0], 2*size[1]
+    sphere_mass = mass*4*r/(4*r + 3*height)
+    cyl_mass = mass - sphere_mass
+    ixx = cyl_mass*(3*r*r + height*height)/12.0
+    izz = cyl_mass*r*r/2.0
+    sphere_i = 2.0*sphere_mass*r*r/5.0
+    ixx += sphere_i + sphere_mass*height*(3*r + 2*height)/8.0
+    izz += sphere_i
+    return np.array([ixx, ixx, izz])
+  if gtype == mdl.GEOM_CYLINDER:
+    r, height = size[0], 2*size[1]
+    ixx = mass*(3*r*r + height*height)/12.0
+    return np.array([ixx, ixx, mass*r*r/2.0])
+  if gtype == mdl.GEOM_ELLIPSOID:
+    a, b, c = size
+    return mass/5.0*np.array([b*b + c*c, a*a + c*c, a*a + b*b])
+  if gtype == mdl.GEOM_BOX:
+    a, b, c = size
+    return mass/3.0*np.array([b*b + c*c, a*a + c*c, a*a + b*b])
+  return np.zeros(3)
+
+
+_GEOM_TYPES = {'plane': mdl.GEOM_PLANE, 'sphere': mdl.GEOM_SPHERE,
+               'capsule': mdl.GEOM_CAPSULE, 'ellipsoid': mdl.GEOM_ELLIPSOID,
+               'cylinder': mdl.GEOM_CYLINDER, 'box': mdl.GEOM_BOX}
+_JNT_TYPES = {'free': mdl.JNT_FREE, 'ball': mdl.JNT_BALL,
+              'slide': mdl.JNT_SLIDE, 'hinge': mdl.JNT_HINGE}
+
+
+class _Compiler:
+
+  def __init__(self, root, assets):
+    self.root = root
+    self.assets = assets
+    self.defaults = _Defaults()
+    self.angle_scale = math.pi/180.0
+    self.eulerseq = 'xyz'
+    self.settotalmass = -1.0
+    self.inertiafromgeom = 'auto'
+    self.bodies = []
+    self.joints = []
+    self.geoms = []
+    self.sites = []
+
+  # -- orientation ------------------------------------------------------------
+  def _orientation(self, attrs, what):
+    given = [k for k in ('quat', 'axisangle', 'euler', 'xyaxes', 'zaxis')
+             if k in attrs]
+    if len(given) > 1:
+      raise CompileError('%s: multiple orientation specifiers %s'
+                         % (what, given))
+    if not given:
+      return np.array([1.0, 0.0, 0.0, 0.0])
+    key = given[0]
+    if key == 'quat':
+      return _normalize(_floats(attrs['quat'], 4, 'quat'))
+    if key == 'axisangle':
+      v = _floats(attrs['axisangle'], 4, 'axisangle')
+      return axis_angle_to_quat(v[:3], v[3]*self.angle_scale)
+    if key == 'euler':
+      e = [a*self.angle_scale for a in _floats(attrs['euler'], 3, 'euler')]
+      q = np.array([1.0, 0.0, 0.0, 0.0])
+      for ch, ang in zip(self.eulerseq, e):
+        axis = {'x': [1, 0, 0], 'y': [0, 1, 0], 'z': [0, 0, 1]}[ch.lower()]
+        r = axis_angle_to_quat(axis, ang)
+        # lower case: rotating (intrinsic) axes; upper case: fixed axes.
+        q = quat_mul(q, r) if ch.islower() else quat_mul(r, q)
+      return q
+    if key == 'xyaxes':
+      v = _floats(attrs['xyaxes'], 6, 'xyaxes')
+      x = _normalize(v[:3])
+      y = np.asarray(v[3:]) - np.dot(x, v[3:])*x
+      y = _normalize(y)
+      z = np.cross(x, y)
+      return mat_to_quat(np.stack([x, y, z], axis=1))
+    return z_to_quat(_floats(attrs['zaxis'], 3, 'zaxis'))
+
+  # -- sections -----------------------------------------------------------------
+  def _parse_compiler(self):
+    for c in self.root.findall('compiler'):
+      if 'angle' in c.attrib:
+        if c.get('angle') not in ('degree', 'radian'):
+          raise CompileError('compiler angle must be degree or radian')
+        self.angle_scale = (math.pi/180.0 if c.get('angle') == 'degree'
+                            else 1.0)
+      if c.get('coordinate', 'local') != 'local':
+        raise CompileError('only coordinate="local" is supported')
+      self.eulerseq = c.get('eulerseq', self.eulerseq)
+      if 'settotalmass' in c.attrib:
+        self.settotalmass = float(c.get('settotalmass'))
+      self.inertiafromgeom = c.get('inertiafromgeom', self.inertiafromgeom)
+      for key in ('boundmass', 'boundinertia'):
+        if float(c.get(key, 0)) != 0:
+          raise CompileError('compiler %s is not supported' % key)
+
+  def _parse_option(self, m):
+    opt = m.opt
+    opt.timestep = 0.002
+    opt.gravity = np.array([0.0, 0.0, -9.81])
+    opt.integrator = mdl.INT_EULER
+    opt.cone = mdl.CONE_PYRAMIDAL
+    opt.solver = mdl.SOLVER_NEWTON
+    opt.iterations = 100
+    opt.tolerance = 1e-8
+    opt.impratio = 1.0
+    opt.disableflags = 0
+    opt.enableflags = 0
+    for o in self.root.findall('option'):
+      a = o.attrib
+      if 'timestep' in a:
+        opt.timestep = float(a['timestep'])
+      if 'gravity' in a:
+        opt.gravity = np.array(_floats(a['gravity'], 3, 'gravity'))
+      if 'integrator' in a:
+        try:
+          opt.integrator = {'Euler': mdl.INT_EULER,
+                            'RK4': mdl.INT_RK4}[a['integrator']]
+        except KeyError:
+          raise CompileError('unknown integrator %r' % a['integrator'])
+      if 'cone' in a:
+        opt.cone = {'pyramidal': mdl.CONE_PYRAMIDAL,
+                    'elliptic': mdl.CONE_ELLIPTIC}[a['cone']]
+      if 'solver' in a:
+        opt.solver = {'PGS': mdl.SOLVER_PGS, 'CG': mdl.SOLVER_CG,
+                      'Newton': mdl.SOLVER_NEWTON}[a['solver']]
+      if 'iterations' in a:
+        opt.iterations = int(a['iterations'])
+      if 'tolerance' in a:
+        opt.tolerance = float(a['tolerance'])
+      if 'impratio' in a:
+        opt.impratio = float(a['impratio'])
+      for key in ('wind', 'density', 'viscosity', 'magnetic'):
+        if key in a and any(v != 0 for v in _floats(a[key])) \
+            and key != 'magnetic':
+          raise CompileError('option %s is not supported' % key)
+      if int(a.get('noslip_iterations', 0)) != 0:
+        raise CompileError('noslip solver is not supported')
+      for f in o.findall('flag'):
+        for name, val in f.attrib.items():
+          if val not in ('enable', 'disable'):
+            raise CompileError('flag %s must be enable/disable' % name)
+          if name in mdl.DISABLE_NAMES:
+            bit = mdl.DISABLE_NAMES[name]
+            if val == 'disable':
+              opt.disableflags |= bit
+            else:
+              opt.disableflags &= ~bit
+          elif name in mdl.ENABLE_NAMES:
+            bit = mdl.ENABLE_NAMES[name]
+            if val == 'enable':
+              opt.enableflags |= bit
+            else:
+              opt.enableflags &= ~bit
+          else:
+            raise CompileError('unknown flag %r' % name)
+    if opt.cone != mdl.CONE_PYRAMIDAL:
+      raise CompileError('only the pyramidal friction cone is implemented')
+
+  def _parse_defaults(self):
+    for d in self.root.findall('default'):
+      cls = d.get('class', 'main')
+      if cls != 'main':
+        raise CompileError('top-level <default> class must be "main"')
+      self.defaults.add(d, 'main', 'main')
+
+  # -- kinematic tree -----------------------------------------------------------
+  def _add_body(self, elem, parent_id, active_class):
+    is_world = parent_id < 0
+    if is_world:
+      body = dict(name='world', parent=0, pos=np.zeros(3),
+                  quat=np.array([1.0, 0, 0, 0]), inertial=None)
+      childclass = None
+    else:
+      childclass = elem.get('childclass', active_class)
+      body = dict(
+          name=elem.get('name'), parent=parent_id,
+          pos=np.array(_floats(elem.get('pos', '0 0 0'), 3, 'body pos')),
+          quat=self._orientation(elem.attrib, 'body'), inertial=None)
+      if elem.get('mocap', 'false') == 'true':
+        raise CompileError('mocap bodies are not supported')
+    body_id = len(self.bodies)
+    self.bodies.append(body)
+    body['joints'], body['geoms'] = [], []
+    child_bodies = []
+    for child in elem:
+      tag = child.tag
+      if tag == 'body':
+        child_bodies.append(child)
+      elif tag in ('joint', 'freejoint'):
+        if is_world:
+          raise CompileError('joints cannot be defined in the world body')
+        body['joints'].append(self._make_joint(child, body_id, childclass))
+      elif tag == 'geom':
+        body['geoms'].append(self._make_geom(child, body_id, childclass))
+      elif tag == 'site':
+        self._make_site(child, body_id, childclass)
+      elif tag == 'inertial':
+        body['inertial'] = self._make_inertial(child)
+      elif tag in _IGNORED_BODY_CHILDREN:
+        continue
+      else:
+        raise CompileError('unsupported element <%s> in body' % tag)
+    for child in child_bodies:
+      self._add_body(child, body_id, childclass)
+
+  def _make_inertial(self, elem):
+    a = elem.attrib
+    mass = float(a['mass'])
+    pos = np.array(_floats(a.get('pos', '0 0 0'), 3, 'inertial pos'))
+    quat = self._orientation(a, 'inertial')
+    if 'fullinertia' in a:
+      f = _floats(a['fullinertia'], 6, 'fullinertia')
+      full = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]],
+                       [f[4], f[5], f[2]]])
+      inertia, rot = _principal(full)
+      quat = quat_mul(quat, mat_to_quat(rot))
+    else:
+      inertia = np.array(_floats(a['diaginertia'], 3, 'diaginertia'))
+    return dict(mass=mass, pos=pos, quat=quat, inertia=inertia)
+
+  def _make_joint(self, elem, body_id, active_class):
+    if elem.tag == 'freejoint':
+      # <freejoint> takes no defaults (MJCF reference, body/freejoint).
+      a = {'type': 'free'}
+      if elem.get('name'):
+        a['name'] = elem.get('name')
+    else:
+      a = self.defaults.resolve(elem, active_class)
+    jtype = _JNT_TYPES.get(a.get('type', 'hinge'))
+    if jtype is None:
+      raise CompileError('unknown joint type %r' % a.get('type'))
+    rot = jtype in (mdl.JNT_HINGE, mdl.JNT_BALL)
+    scale = self.angle_scale if rot else 1.0
+    rng = _floats(a.get('range', '0 0'), 2, 'joint range')
+    if float(a.get('frictionloss', 0)) != 0:
+      raise CompileError('joint frictionloss is not supported')
+    j = dict(
+        name=a.get('name'), type=jtype, body=body_id,
+        pos=np.array(_floats(a.get('pos', '0 0 0'), 3, 'joint pos')),
+        axis=(np.array([0.0, 0.0, 1.0]) if jtype in (mdl.JNT_FREE,
+                                                     mdl.JNT_BALL)
+              else _normalize(_floats(a.get('axis', '0 0 1'), 3, 'axis'))),
+        limited=_bool(a.get('limited', 'false'), 'joint limited'),
+        range=np.array(rng)*scale,
+        ref=float(a.get('ref', 0))*scale,
+        springref=float(a.get('springref', 0))*scale,
+        stiffness=float(a.get('stiffness', 0)),
+        damping=float(a.get('damping', 0)),
+        armature=float(a.get('armature', 0)),
+        margin=float(a.get('margin', 0))*scale,
+        solref=_solref(a.get('solreflimit')),
+        solimp=_solimp(a.get('solimplimit')))
+    if jtype == mdl.JNT_FREE and self.bodies[body_id]['parent'] != 0:
+      raise CompileError('free joint can only be used on top level')
+    if jtype in (mdl.JNT_FREE, mdl.JNT_BALL) and j['stiffness'] != 0:
+      raise CompileError('stiffness on free/ball joints is not supported')
+    if jtype == mdl.JNT_BALL and j['limited']:
+      raise CompileError('limited ball joints are not supported')
+    return j
+
+  def _make_geom(self, elem, body_id, active_class):
+    a = self.defaults.resolve(elem, active_class)
+    tname = a.get('type', 'sphere')
+    if tname not in _GEOM_TYPES:
+      raise CompileError('geom type %r is not supported' % tname)
+    gtype = _GEOM_TYPES[tname]
+    size = _floats(a.get('size', '0 0 0'))
+    size = (size + [0.0, 0.0, 0.0])[:3]
+    pos = np.array(_floats(a.get('pos', '0 0 0'), 3, 'geom pos'))
+    quat = self._orientation(a, 'geom')
+    if 'fromto' in a:
+      if gtype not in (mdl.GEOM_CAPSULE, mdl.GEOM_CYLINDER, mdl.GEOM_BOX,
+                       mdl.GEOM_ELLIPSOID):
+        raise CompileError('fromto requires capsule/cylinder/box/ellipsoid')
+      ft = np.array(_floats(a['fromto'], 6, 'fromto'))
+      vec = ft[:3] - ft[3:]
+      half = 0.5*np.linalg.norm(vec)
+      if gtype in (mdl.GEOM_CAPSULE, mdl.GEOM_CYLINDER):
+        size[1] = half
+      else:
+        size[2] = half
+      pos = 0.5*(ft[:3] + ft[3:])
+      quat = z_to_quat(vec)
+    need = {mdl.GEOM_SPHERE: 1, mdl.GEOM_CAPSULE: 2, mdl.GEOM_CYLINDER: 2,
+            mdl.GEOM_ELLIPSOID: 3, mdl.GEOM_BOX: 3, mdl.GEOM_PLANE: 0}[gtype]
+    if any(s <= 0 for s in size[:need]):
+      raise CompileError('geom %r: size must be positive' % a.get('name'))
+    fr = _floats(a.get('friction', '1 0.005 0.0001'))
+    fr = (fr + [1.0, 0.005, 0.0001][len(fr):])[:3]
+    g = dict(
+        name=a.get('name'), type=gtype, body=body_id, size=np.array(size),
+        pos=pos, quat=quat,
+        contype=int(a.get('contype', 1)),
+        conaffinity=int(a.get('conaffinity', 1)),
+        condim=int(a.get('condim', 3)), priority=int(a.get('priority', 0)),
+        friction=np.array(fr), solmix=float(a.get('solmix', 1)),
+        solref=_solref(a.get('solref')), solimp=_solimp(a.get('solimp')),
+        margin=float(a.get('margin', 0)), gap=float(a.get('gap', 0)),
+        mass=float(a['mass']) if 'mass' in a else None,
+        density=float(a.get('density', 1000)))
+    if g['condim'] not in (1, 3, 4, 6):
+      raise CompileError('condim must be 1, 3, 4 or 6')
+    return g
+
+  def _make_site(self, elem, body_id, active_class):
+    a = self.defaults.resolve(elem, active_class)
+    pos = np.array(_floats(a.get('pos', '0 0 0'), 3, 'site pos'))
+    quat = self._orientation(a, 'site')
+    if 'fromto' in a:
+      ft = np.array(_floats(a['fromto'], 6, 'fromto'))
+      pos = 0.5*(ft[:3] + ft[3:])
+      quat = z_to_quat(ft[:3] - ft[3:])
+    self.sites.append(dict(name=a.get('name'), body=body_id, pos=pos,
+                           quat=quat))
+
+  # -- assembly -----------------------------------------------------------------
+  def compile(self):
+    root = self.root
+    if root.tag != 'mujoco':
+      raise CompileError('root element must be <mujoco>')
+    _expand_includes(root, self.assets)
+    for sec in _UNSUPPORTED_SECTIONS:
+      for e in root.findall(sec):
+        if len(e):
+          raise CompileError('<%s> is not supported' % sec)
+    known = set(_UNSUPPORTED_SECTIONS + _IGNORED_SECTIONS + (
+        'compiler', 'option', 'default', 'worldbody', 'actuator', 'sensor',
+        'contact'))
+    for e in root:
+      if e.tag not in known:
+        raise CompileError('unknown top-level element <%s>' % e.tag)
+
+    m = mdl.Model()
+    m.modelname = root.get('model', 'MuJoCo Model')
+    self._parse_compiler()
+    self._parse_option(m)
+    self._parse_defaults()
+
+    worlds = root.findall('worldbody')
+    if not worlds:
+      raise CompileError('missing <worldbody>')
+    world = ET.Element('worldbody')
+    for w in worlds:
+      world.extend(list(w))
+    self._add_body(world, -1, None)
+
+    self._finish_tree(m)
+    self._finish_actuators(m)
+    self._finish_sensors(m)
+    self._finish_contact(m)
+    _set_const(m)
+    return m
+
+  def _finish_tree(self, m):
+    bodies = self.bodies
+    nbody = len(bodies)
+    m.nbody = nbody
+    joints, geoms = [], []
+    for b in bodies:
+      b['jntadr'], b['jntnum'] = len(joints), len(b['joints'])
+      joints.extend(b['joints'])
+      b['geomadr'], b['geomnum'] = len(geoms), len(b['geoms'])
+      geoms.extend(b['geoms'])
+    m.njnt, m.ngeom = len(joints), len(geoms)
+
+    m.body_parentid = np.array([b['parent'] for b in bodies], np.int32)
+    m.body_pos = np.array([b['pos'] for b in bodies]).reshape(nbody, 3)
+    m.body_quat = np.array([b['quat'] for b in bodies]).reshape(nbody, 4)
+    m.body_jntnum = np.array([b['jntnum'] for b in bodies], np.int32)
+    m.body_jntadr = np.array(
+        [b['jntadr'] if b['jntnum'] else -1 for b in bodies], np.int32)
+    m.body_geomnum = np.array([b['geomnum'] for b in bodies], np.int32)
+    m.body_geomadr = np.array(
+        [b['geomadr'] if b['geomnum'] else -1 for b in bodies], np.int32)
+
+    # joints, qpos/dof addresses
+    nq = nv = 0
+    qpos0, qpos_spring = [], []
+    dof_body, dof_jnt, dof_arm, dof_damp = [], [], [], []
+    for jid, j in enumerate(joints):
+      j['qposadr'], j['dofadr'] = nq, nv
+      b = bodies[j['body']]
+      if j['type'] == mdl.JNT_FREE:
+        if b['jntnum'] != 1:
+          raise CompileError('free joint must be the only joint of its body')
+        q0 = list(b['pos']) + list(b['quat'])
+        nqj, nvj = 7, 6
+        qs = q0
+      elif j['type'] == mdl.JNT_BALL:
+        q0, nqj, nvj = [1.0, 0.0, 0.0, 0.0], 4, 3
+        qs = q0
+      else:
+        q0, nqj, nvj = [j['ref']], 1, 1
+        qs = [j['springref']]
+      qpos0.extend(q0)
+      qpos_spring.extend(qs)
+      nq += nqj
+      for _ in range(nvj):
+        dof_body.append(j['body'])
+        dof_jnt.append(jid)
+        dof_arm.append(j['armature'])
+        dof_damp.append(j['damping'])
+      nv += nvj
+    m.nq, m.nv = nq, nv
+    m.qpos0 = np.array(qpos0, np.float64)
+    m.qpos_spring = np.array(qpos_spring, np.float64)
+
+    def arr(key, shape, dtype=np.float64, src=joints):
+      return np.array([x[key] for x in src], dtype).reshape(shape)
+    nj = m.njnt
+    m.jnt_type = arr('type', (nj,), np.int32)
+    m.jnt_qposadr = arr('qposadr', (nj,), np.int32)
+    m.jnt_dofadr = arr('dofadr', (nj,), np.int32)
+    m.jnt_bodyid = arr('body', (nj,), np.int32)
+    m.jnt_limited = np.array([int(j['limited']) for j in joints], np.int32)
+    m.jnt_pos = arr('pos', (nj, 3))
+    m.jnt_axis = arr('axis', (nj, 3))
+    m.jnt_stiffness = arr('stiffness', (nj,))
+    m.jnt_range = arr('range', (nj, 2))
+    m.jnt_margin = arr('margin', (nj,))
+    m.jnt_solref = arr('solref', (nj, 2))
+    m.jnt_solimp = arr('solimp', (nj, 5))
+
+    m.dof_bodyid = np.array(dof_body, np.int32)
+    m.dof_jntid = np.array(dof_jnt, np.int32)
+    m.dof_armature = np.array(dof_arm, np.float64)
+    m.dof_damping = np.array(dof_damp, np.float64)
+    m.body_dofnum = np.zeros(nbody, np.int32)
+    m.body_dofadr = np.full(nbody, -1, np.int32)
+    for d, b in enumerate(dof_body):
+      if m.body_dofnum[b] == 0:
+        m.body_dofadr[b] = d
+      m.body_dofnum[b] += 1
+    # dof_parentid: previous dof of the same body, else the last dof of the
+    # nearest ancestor that has any.
+    m.dof_parentid = np.full(nv, -1, np.int32)
+    for d in range(nv):
+      b = dof_body[d]
+      if d > m.body_dofadr[b]:
+        m.dof_parentid[d] = d - 1
+      else:
+        p = m.body_parentid[b]
+        while p > 0 and m.body_dofnum[p] == 0:
+          p = m.body_parentid[p]
+        if p > 0:
+          m.dof_parentid[d] = m.body_dofadr[p] + m.body_dofnum[p] - 1
+
+    # root / weld ids
+    m.body_rootid = np.zeros(nbody, np.int32)
+    m.body_weldid = np.zeros(nbody, np.int32)
+    for i in range(1, nbody):
+      p = m.body_parentid[i]
+      m.body_rootid[i] = i if p == 0 else m.body_rootid[p]
+      m.body_weldid[i] = i if m.body_jntnum[i] > 0 else m.body_weldid[p]
+
+    # geoms
+    ng = m.ngeom
+    def garr(key, shape, dtype=np.float64):
+      return np.array([g[key] for g in geoms], dtype).reshape(shape)
+    m.geom_type = garr('type', (ng,), np.int32)
+    m.geom_contype = garr('contype', (ng,), np.int32)
+    m.geom_conaffinity = garr('conaffinity', (ng,), np.int32)
+    m.geom_condim = garr('condim', (ng,), np.int32)
+    m.geom_priority = garr('priority', (ng,), np.int32)
+    m.geom_bodyid = garr('body', (ng,), np.int32)
+    m.geom_size = garr('size', (ng, 3))
+    m.geom_pos = garr('pos', (ng, 3))
+    m.geom_quat = garr('quat', (ng, 4))
+    m.geom_friction = garr('friction', (ng, 3))
+    m.geom_solmix = garr('solmix', (ng,))
+    m.geom_solref = garr('solref', (ng, 2))
+    m.geom_solimp = garr('solimp', (ng, 5))
+    m.geom_margin = garr('margin', (ng,))
+    m.geom_gap = garr('gap', (ng,))
+    rb = np.zeros(ng)
+    for i, g in enumerate(geoms):
+      s, t = g['size'], g['type']
+      if t == mdl.GEOM_SPHERE:
+        rb[i] = s[0]
+      elif t == mdl.GEOM_CAPSULE:
+        rb[i] = s[0] + s[1]
+      elif t == mdl.GEOM_CYLINDER:
+        rb[i] = math.hypot(s[0], s[1])
+      elif t in (mdl.GEOM_BOX, mdl.GEOM_ELLIPSOID):
+        rb[i] = (np.linalg.norm(s) if t == mdl.GEOM_BOX else max(s))
+    m.geom_rbound = rb
+
+    # body inertial properties
+    m.body_mass = np.zeros(nbody)
+    m.body_inertia = np.zeros((nbody, 3))
+    m.body_ipos = np.zeros((nbody, 3))
+    m.body_iquat = np.tile([1.0, 0, 0, 0], (nbody, 1))
+    for i, b in enumerate(bodies):
+      explicit = b['inertial']
+      use_geoms = (self.inertiafromgeom == 'true' or
+                   (self.inertiafromgeom == 'auto' and explicit is None))
+      if i == 0:
+        continue
+      if not use_geoms:
+        if explicit is None:
+          continue
+        m.body_mass[i] = explicit['mass']
+        m.body_ipos[i] = explicit['pos']
+        m.body_iquat[i] = explicit['quat']
+        m.body_inertia[i] = explicit['inertia']
+        continue
+      masses, coms, tensors = [], [], []
+      for g in b['geoms']:
+        if g['type'] == mdl.GEOM_PLANE:
+          continue
+        gm = (g['mass'] if g['mass'] is not None
+              else g['density']*_geom_volume(g['type'], g['size']))
+        gi = _geom_inertia(g['type'], g['size'], gm)
+        r = quat_to_mat(g['quat'])
+        masses.append(gm)
+        coms.append(g['pos'])
+        tensors.append(r @ np.diag(gi) @ r.T)
+      if not masses:
+        continue
+      mass = float(sum(masses))
+      if mass <= 0:
+        continue
+      com = sum(mm*c for mm, c in zip(masses, coms))/mass
+      full = np.zeros((3, 3))
+      for mm, c, t in zip(masses, coms, tensors):
+        d = c - com
+        full += t + mm*(np.dot(d, d)*np.eye(3) - np.outer(d, d))
+      if len(masses) == 1:
+        # single geom: the geom frame already is the principal frame
+        g = [g for g in b['geoms'] if g['type'] != mdl.GEOM_PLANE][0]
+        inertia = _geom_inertia(g['type'], g['size'], mass)
+        iquat = g['quat']
+      else:
+        inertia, rot = _principal(full)
+        iquat = mat_to_quat(rot)
+      m.body_mass[i] = mass
+      m.body_ipos[i] = com
+      m.body_iquat[i] = iquat
+      m.body_inertia[i] = inertia
+    for i in range(1, nbody):
+      if m.body_dofnum[i] > 0 and m.body_mass[i] <= 0 and not any(
+          m.body_mass[c] > 0 for c in range(i + 1, nbody)
+          if _is_descendant(m.body_parentid, c, i)):
+        raise CompileError('mass and inertia of moving bodies must be '
+                           'positive (body %r)' % bodies[i]['name'])
+    if self.settotalmass > 0:
+      total = m.body_mass.sum()
+      if total > 0:
+        s = self.settotalmass/total
+        m.body_mass *= s
+        m.body_inertia *= s
+
+    m.names = {
+        'body': [b['name'] for b in bodies],
+        'joint': [j['name'] for j in joints],
+        'geom': [g['name'] for g in geoms],
+        'site': [s['name'] for s in self.sites],
+    }
+    m.nsite = len(self.sites)
+    m.site_bodyid = np.array([s['body'] for s in self.sites], np.int32)
+    m.site_pos = np.array([s['pos'] for s in self.sites]).reshape(-1, 3)
+    m.site_quat = np.array([s['quat'] for s in self.sites]).reshape(-1, 4)
+    self.joints, self.geoms = joints, geoms
+
+  def _finish_actuators(self, m):
+    acts = []
+    for sec in self.root.findall('actuator'):
+      for e in sec:
+        if e.tag not in _ACTUATOR_TAGS:
+          raise CompileError('actuator <%s> is not supported' % e.tag)
+        a = self.defaults.resolve(e, None)
+        if 'joint' not in a:
+          raise CompileError('only joint transmissions are supported')
+        jid = m.name2id(a['joint'], 'joint')
+        if m.jnt_type[jid] not in (mdl.JNT_HINGE, mdl.JNT_SLIDE):
+          raise CompileError('actuators on free/ball joints not supported')
+        gear = _floats(a.get('gear', '1'))[0]
+        gain = [1.0, 0.0, 0.0]
+        bias = [0.0, 0.0, 0.0]
+        gaintype, biastype = mdl.GAIN_FIXED, mdl.BIAS_NONE
+        if e.tag == 'position':
+          kp = float(a.get('kp', 1))
+          gain[0], bias[1], biastype = kp, -kp, mdl.BIAS_AFFINE
+        elif e.tag == 'velocity':
+          kv = float(a.get('kv', 1))
+          gain[0], bias[2], biastype = kv, -kv, mdl.BIAS_AFFINE
+        elif e.tag == 'general':
+          if a.get('dyntype', 'none') != 'none':
+            raise CompileError('actuator dynamics are not supported')
+          if a.get('gaintype', 'fixed') != 'fixed':
+            raise CompileError('only gaintype="fixed" is supported')
+          g = _floats(a.get('gainprm', '1'))
+          gain = (g + [0.0, 0.0, 0.0])[:3]
+          bt = a.get('biastype', 'none')
+          if bt == 'affine':
+            bb = _floats(a.get('biasprm', '0'))
+            bias = (bb + [0.0, 0.0, 0.0])[:3]
+            biastype = mdl.BIAS_AFFINE
+          elif bt != 'none':
+            raise CompileError('biastype %r not supported' % bt)
+        acts.append(dict(
+            name=a.get('name'), trnid=jid, gear=gear, gain=gain, bias=bias,
+            gaintype=gaintype, biastype=biastype,
+            ctrllimited=_bool(a.get('ctrllimited', 'false'), 'ctrllimited'),
+            ctrlrange=_floats(a.get('ctrlrange', '0 0'), 2, 'ctrlrange'),
+            forcelimited=_bool(a.get('forcelimited', 'false'),
+                               'forcelimited'),
+            forcerange=_floats(a.get('forcerange', '0 0'), 2, 'forcerange')))
+    nu = len(acts)
+    m.nu = nu
+    m.actuator_trntype = np.full(nu, mdl.TRN_JOINT, np.int32)
+    m.actuator_trnid = np.array([a['trnid'] for a in acts], np.int32)
+    m.actuator_ctrllimited = np.array([int(a['ctrllimited']) for a in acts],
+                                      np.int32)
+    m.actuator_forcelimited = np.array(
+        [int(a['forcelimited']) for a in acts], np.int32)
+    m.actuator_gaintype = np.array([a['gaintype'] for a in acts], np.int32)
+    m.actuator_biastype = np.array([a['biastype'] for a in acts], np.int32)
+    m.actuator_gear = np.array([a['gear'] for a in acts], np.float64)
+    m.actuator_ctrlrange = np.array(
+        [a['ctrlrange'] for a in acts], np.float64).reshape(nu, 2)
+    m.actuator_forcerange = np.array(
+        [a['forcerange'] for a in acts], np.float64).reshape(nu, 2)
+    m.actuator_gainprm = np.array(
+        [a['gain'] for a in acts], np.float64).reshape(nu, 3)
+    m.actuator_biasprm = np.array(
+        [a['bias'] for a in acts], np.float64).reshape(nu, 3)
+    m.names['actuator'] = [a['name'] for a in acts]
+
+  def _finish_sensors(self, m):
+    types, objids, adrs, dims, names = [], [], [], [], []
+    adr = 0
+    for sec in self.root.findall('sensor'):
+      for e in sec:
+        if e.tag not in mdl.SENSOR_TYPES:
+          raise CompileError('sensor <%s> is not supported' % e.tag)
+        code, dim = mdl.SENSOR_TYPES[e.tag]
+        if 'site' in e.attrib:
+          objid = m.name2id(e.get('site'), 'site')
+        elif 'body' in e.attrib:
+          objid = m.name2id(e.get('body'), 'body')
+        elif 'joint' in e.attrib:
+          objid = m.name2id(e.get('joint'), 'joint')
+        elif 'actuator' in e.attrib:
+          objid = m.name2id(e.get('actuator'), 'actuator')
+        else:
+          objid = -1
+        types.append(code)
+        objids.append(objid)
+        adrs.append(adr)
+        dims.append(dim)
+        names.append(e.get('name'))
+        adr += dim
+    m.nsensor, m.nsensordata = len(types), adr
+    m.sensor_type = np.array(types, np.int32)
+    m.sensor_objid = np.array(objids, np.int32)
+    m.sensor_adr = np.array(adrs, np.int32)
+    m.sensor_dim = np.array(dims, np.int32)
+    m.names['sensor'] = names
+
+  def _finish_contact(self, m):
+    sigs = []
+    for sec in self.root.findall('contact'):
+      for e in sec:
+        if e.tag == 'exclude':
+          b1 = m.name2id(e.get('body1'), 'body')
+          b2 = m.name2id(e.get('body2'), 'body')
+          sigs.append((min(b1, b2) << 16) + max(b1, b2))
+        else:
+          raise CompileError('<contact><%s> is not supported' % e.tag)
+    m.nexclude = len(sigs)
+    m.exclude_signature = np.array(sigs, np.int32)
+
+
+def _is_descendant(parentid, c, anc):
+  while c > 0:
+    c = parentid[c]
+    if c == anc:
+      return True
+  return False
+
+
+def _principal(full):
+  """Symmetric 3x3 -> (principal moments, rotation with det +1)."""
+  off = abs(full[0, 1]) + abs(full[0, 2]) + abs(full[1, 2])
+  if off <= 1e-14*max(1e-300, np.trace(full)):
+    return np.diag(full).copy(), np.eye(3)
+  w, v = np.linalg.eigh(full)
+  order = np.argsort(-w)
+  w, v = w[order], v[:, order]
+  if np.linalg.det(v) < 0:
+    v[:, 2] = -v[:, 2]
+  return w, v
+
+
+def _solref(text):
+  vals = _floats(text) if text else []
+  return np.array((vals + [0.02, 1.0][len(vals):])[:2])
+
+
+def _solimp(text):
+  vals = _floats(text) if text else []
+  return np.array((vals + [0.9, 0.95, 0.001, 0.5, 2.0][len(vals):])[:5])
+
+
+# ----------------------------------------------------------------------------
+# mj_setConst equivalents ("mj_setConst")
+# ----------------------------------------------------------------------------
+def kinematics_qpos0(m):
+  """World poses at `qpos0` (joint displacements are zero by definition)."""
+  nb = m.nbody
+  xpos = np.zeros((nb, 3))
+  xquat = np.tile([1.0, 0, 0, 0], (nb, 1))
+  for i in range(1, nb):
+    p = m.body_parentid[i]
+    rp = quat_to_mat(xquat[p])
+    xpos[i] = xpos[p] + rp @ m.body_pos[i]
+    xquat[i] = quat_mul(xquat[p], m.body_quat[i])
+    xquat[i] /= np.linalg.norm(xquat[i])
+  xmat = np.array([quat_to_mat(q) for q in xquat])
+  xipos = np.array([xpos[i] + xmat[i] @ m.body_ipos[i] for i in range(nb)])
+  ximat = np.array([quat_to_mat(quat_mul(xquat[i], m.body_iquat[i]))
+                    for i in range(nb)])
+  xanchor = np.zeros((m.njnt, 3))
+  xaxis = np.zeros((m.njnt, 3))
+  for j in range(m.njnt):
+    b = m.jnt_bodyid[j]
+    xanchor[j] = xpos[b] + xmat[b] @ m.jnt_pos[j]
+    xaxis[j] = xmat[b] @ m.jnt_axis[j]
+  return xpos, xquat, xmat, xipos, ximat, xanchor, xaxis
+
+
+def _body_jacobian(m, body, point, xmat, xanchor, xaxis, xpos):
+  """6 x nv Jacobian (linear rows first) of `point` fixed to `body`."""
+  jac = np.zeros((6, m.nv))
+  b = body
+  while b > 0 and m.body_dofnum[b] == 0:
+    b = m.body_parentid[b]
+  if b == 0:
+    return jac
+  d = m.body_dofadr[b] + m.body_dofnum[b] - 1
+  while d >= 0:
+    j = m.dof_jntid[d]
+    t = m.jnt_type[j]
+    k = d - m.jnt_dofadr[j]
+    if t == mdl.JNT_SLIDE:
+      jac[:3, d] = xaxis[j]
+    elif t == mdl.JNT_HINGE:
+      jac[3:, d] = xaxis[j]
+      jac[:3, d] = np.cross(xaxis[j], point - xanchor[j])
+    elif t == mdl.JNT_FREE and k < 3:
+      jac[k, d] = 1.0
+    else:
+      kk = k - 3 if t == mdl.JNT_FREE else k
+      jb = m.jnt_bodyid[j]
+      axis = xmat[jb][:, kk]
+      jac[3:, d] = axis
+      jac[:3, d] = np.cross(axis, point - xanchor[j])
+    d = m.dof_parentid[d]
+  return jac
+
+
+def mass_matrix_qpos0(m):
+  """Dense joint-space inertia at `qpos0` as a sum over bodies."""
+  xpos, _, xmat, xipos, ximat, xanchor, xaxis = kinematics_qpos0(m)
+  mm = np.diag(m.dof_armature.astype(np.float64)) if m.nv else np.zeros((0, 0))
+  jacs = []
+  for b in range(m.nbody):
+    jac = _body_jacobian(m, b, xipos[b], xmat, xanchor, xaxis, xpos)
+    jacs.append(jac)
+    if b == 0 or m.body_mass[b] == 0:
+      continue
+    iw = ximat[b] @ np.diag(m.body_inertia[b]) @ ximat[b].T
+    mm = mm + m.body_mass[b]*jac[:3].T @ jac[:3] + jac[3:].T @ iw @ jac[3:]
+  return mm, jacs
+
+
+def _set_const(m):
+  nb = m.nbody
+  m.body_subtreemass = m.body_mass.copy()
+  for i in range(nb - 1, 0, -1):
+    m.body_subtreemass[m.body_parentid[i]] += m.body_subtreemass[i]
+  m.dof_invweight0 = np.zeros(m.nv)
+  m.body_invweight0 = np.zeros((nb, 2))
+  m.meaninertia = 1.0
+  if m.nv == 0:
+    m.opt.meaninertia = 1.0
+    return
+  mm, jacs = mass_matrix_qpos0(m)
+  try:
+    minv = np.linalg.inv(mm)
+  except np.linalg.LinAlgError:
+    raise CompileError('mass matrix is singular at qpos0')
+  if not np.all(np.linalg.eigvalsh(mm) > 0):
+    raise CompileError('mass matrix is not positive definite at qpos0')
+  m.meaninertia = float(np.mean(np.diag(mm)))
+  diag = np.diag(minv).copy()
+  for j in range(m.njnt):
+    a = m.jnt_dofadr[j]
+    t = m.jnt_type[j]
+    if t == mdl.JNT_FREE:
+      diag[a:a+3] = diag[a:a+3].mean()
+      diag[a+3:a+6] = diag[a+3:a+6].mean()
+    elif t == mdl.JNT_BALL:
+      diag[a:a+3] = diag[a:a+3].mean()
+  m.dof_invweight0 = np.maximum(diag, mdl.MJ_MINVAL)
+  for b in range(1, nb):
+    if m.body_weldid[b] == 0:
+      continue
+    a = jacs[b] @ minv @ jacs[b].T
+    m.body_invweight0[b, 0] = max(mdl.MJ_MINVAL, np.trace(a[:3, :3])/3)
+    m.body_invweight0[b, 1] = max(mdl.MJ_MINVAL, np.trace(a[3:, 3:])/3)
+
+
+# ----------------------------------------------------------------------------
+# public entry points
+# ----------------------------------------------------------------------------
+def from_xml_string(xml_string, assets=None):
+  """Compiles an MJCF string (cf. `MjModel.from_xml_string`, core.py:475-490)."""
+  if isinstance(xml_string, bytes):
+    xml_string = xml_string.decode('utf-8')
+  try:
+    root = ET.fromstring(xml_string)
+  except ET.ParseError as e:
+    raise CompileError('XML parse error: %s' % e)
+  m = _Compiler(root, assets or {}).compile()
+  # mirror the `model.opt` fields at the top level for the native-field table
+  for key in ('timestep', 'gravity', 'integrator', 'cone', 'solver',
+              'iterations', 'tolerance', 'impratio', 'disableflags',
+              'enableflags'):
+    setattr(m, key, getattr(m.opt, key))
+  m.opt.meaninertia = m.meaninertia
+  return m
+
+
+def from_xml_path(path):
+  import os
+  with open(path, 'r') as f:
+    text = f.read()
+  base = os.path.dirname(os.path.abspath(path))
+
+  class _Dir(dict):
+    """Lazy asset lookup relative to the model file."""
+
+    def __bool__(self):
+      return True
+
+    def __contains__(self, key):
+      return os.path.exists(os.path.join(base, key))
+
+    def __getitem__(self, key):
+      with open(os.path.join(base, key), 'rb') as g:
+        return g.read()
+
+    def items(self):
+      return []
+  return from_xml_string(text, _Dir())
