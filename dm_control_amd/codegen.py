@@ -1,0 +1,292 @@
+"""Model -> generated C++ constants header for the HIP kernels.
+
+The device code (csrc/dmc_kernels.hip) is hand-written once; what differs per
+model is a table of compile-time constants: tree topology, inertias, the static
+list of geom pairs that can ever collide (with their mixed contact parameters)
+and the limited joints.  Emitting them as `static __device__ constexpr` arrays
+lets hipcc fold topology into straight-line code for small models.
+
+Host-side logic restated here (independently of oracle/mjstep.c):
+  * collision filtering: contype/conaffinity, same weld group, parent-child,
+    <exclude>  (SURVEY.md Appendix A "collision")
+  * contact parameter mixing for equal priority: condim/friction = max,
+    solref/solimp weighted by solmix, margin/gap = max
+  * stiffness/damping of the constraint reference: b = 2/(dmax*tc),
+    k = 1/(dmax^2 tc^2 zeta^2), tc >= 2*dt (refsafe)
+"""
+
+import numpy as np
+
+from dm_control_amd.mjcf import model as mdl
+
+TASK_NONE, TASK_CARTPOLE, TASK_CHEETAH, TASK_HUMANOID = 0, 1, 2, 3
+
+_SUPPORTED_PAIRS = {
+    (mdl.GEOM_PLANE, mdl.GEOM_SPHERE), (mdl.GEOM_PLANE, mdl.GEOM_CAPSULE),
+    (mdl.GEOM_PLANE, mdl.GEOM_BOX), (mdl.GEOM_SPHERE, mdl.GEOM_SPHERE),
+    (mdl.GEOM_SPHERE, mdl.GEOM_CAPSULE), (mdl.GEOM_CAPSULE, mdl.GEOM_CAPSULE),
+}
+
+
+class UnsupportedModelError(ValueError):
+  pass
+
+
+def _sanitise_solimp(s):
+  return [float(np.clip(s[0], mdl.MJ_MINIMP, mdl.MJ_MAXIMP)),
+          float(np.clip(s[1], mdl.MJ_MINIMP, mdl.MJ_MAXIMP)),
+          float(max(0.0, s[2])),
+          float(np.clip(s[3], mdl.MJ_MINIMP, mdl.MJ_MAXIMP)),
+          float(max(1.0, s[4]))]
+
+
+def _kb(solref, solimp, timestep, refsafe):
+  tc, dr = float(solref[0]), float(solref[1])
+  dmax = float(np.clip(solimp[1], mdl.MJ_MINIMP, mdl.MJ_MAXIMP))
+  if tc > 0:
+    if refsafe:
+      tc = max(tc, 2*timestep)
+    k = 1/max(mdl.MJ_MINVAL, dmax*dmax*tc*tc*dr*dr)
+    b = 2/max(mdl.MJ_MINVAL, dmax*tc)
+  else:
+    k = -tc/max(mdl.MJ_MINVAL, dmax*dmax)
+    b = -dr/max(mdl.MJ_MINVAL, dmax)
+  return k, b
+
+
+def collision_pairs(m):
+  """Static list of geom pairs that pass MuJoCo's filters, type-ordered."""
+  pairs = []
+  if m.opt.disableflags & (mdl.DSBL_CONTACT | mdl.DSBL_CONSTRAINT):
+    return pairs
+  excl = set(int(s) for s in np.atleast_1d(m.exclude_signature)[:m.nexclude])
+  for ga in range(m.ngeom):
+    for gb in range(ga + 1, m.ngeom):
+      ta, tb = int(m.geom_type[ga]), int(m.geom_type[gb])
+      if ta == mdl.GEOM_PLANE and tb == mdl.GEOM_PLANE:
+        continue
+      if not ((m.geom_contype[ga] & m.geom_conaffinity[gb]) or
+              (m.geom_contype[gb] & m.geom_conaffinity[ga])):
+        continue
+      b1, b2 = int(m.geom_bodyid[ga]), int(m.geom_bodyid[gb])
+      w1, w2 = int(m.body_weldid[b1]), int(m.body_weldid[b2])
+      if w1 == w2:
+        continue
+      if not (m.opt.disableflags & mdl.DSBL_FILTERPARENT) and w1 and w2:
+        pw1 = int(m.body_weldid[m.body_parentid[w1]])
+        pw2 = int(m.body_weldid[m.body_parentid[w2]])
+        if w1 == pw2 or w2 == pw1:
+          continue
+      if (min(b1, b2) << 16) + max(b1, b2) in excl:
+        continue
+      g1, g2 = (ga, gb) if ta <= tb else (gb, ga)
+      key = (int(m.geom_type[g1]), int(m.geom_type[g2]))
+      if key not in _SUPPORTED_PAIRS:
+        raise UnsupportedModelError(
+            'collision between geom types %s is not implemented (geoms %r, %r)'
+            % (key, m.names['geom'][g1], m.names['geom'][g2]))
+      pairs.append((g1, g2))
+  return pairs
+
+
+def mix_pair(m, g1, g2):
+  """Mixed contact parameters of a geom pair (equal or unequal priority)."""
+  if m.geom_priority[g1] != m.geom_priority[g2]:
+    gp = g1 if m.geom_priority[g1] > m.geom_priority[g2] else g2
+    dim = int(m.geom_condim[gp])
+    f = m.geom_friction[gp]
+    solref = m.geom_solref[gp].copy()
+    solimp = m.geom_solimp[gp].copy()
+  else:
+    dim = int(max(m.geom_condim[g1], m.geom_condim[g2]))
+    f = np.maximum(m.geom_friction[g1], m.geom_friction[g2])
+    s1, s2 = float(m.geom_solmix[g1]), float(m.geom_solmix[g2])
+    if s1 >= mdl.MJ_MINVAL and s2 >= mdl.MJ_MINVAL:
+      mix = s1/(s1 + s2)
+    elif s1 < mdl.MJ_MINVAL and s2 < mdl.MJ_MINVAL:
+      mix = 0.5
+    else:
+      mix = 0.0 if s1 < mdl.MJ_MINVAL else 1.0
+    if m.geom_solref[g1][0] > 0 and m.geom_solref[g2][0] > 0:
+      solref = mix*m.geom_solref[g1] + (1 - mix)*m.geom_solref[g2]
+    else:
+      solref = np.minimum(m.geom_solref[g1], m.geom_solref[g2])
+    solimp = mix*m.geom_solimp[g1] + (1 - mix)*m.geom_solimp[g2]
+  margin = float(max(m.geom_margin[g1], m.geom_margin[g2]))
+  gap = float(max(m.geom_gap[g1], m.geom_gap[g2]))
+  friction = [float(f[0]), float(f[0]), float(f[1]), float(f[2]), float(f[2])]
+  return dict(dim=dim, friction=friction, solref=solref, solimp=solimp,
+              margin=margin, includemargin=margin - gap)
+
+
+def _fmt(vals, kind):
+  vals = list(np.asarray(vals).ravel())
+  if not vals:
+    vals = [0]
+  if kind == 'int':
+    return ', '.join(str(int(v)) for v in vals)
+  return ', '.join(repr(float(v)) for v in vals)
+
+
+def task_bodies(m, task):
+  if task == TASK_CHEETAH:
+    return [m.name2id('torso', 'body')]
+  if task == TASK_HUMANOID:
+    return [m.name2id(n, 'body') for n in
+            ('torso', 'head', 'left_hand', 'left_foot', 'right_hand',
+             'right_foot')]
+  return [0]
+
+
+def observation_size(m, task):
+  if task == TASK_CARTPOLE:
+    return 1 + 2*(m.nbody - 2) + m.nv
+  if task == TASK_CHEETAH:
+    return (m.nq - 1) + m.nv
+  if task == TASK_HUMANOID:
+    return (m.nq - 7) + 1 + 12 + 3 + 3 + m.nv
+  return m.nq + m.nv
+
+
+def capacities(m, pairs, ncon_max=None):
+  """Contact / constraint-row capacities of the per-env workspace."""
+  per_pair = {mdl.GEOM_CAPSULE: 2, mdl.GEOM_BOX: 4}
+  worst = 0
+  worst_rows = 0
+  mixed = [mix_pair(m, g1, g2) for g1, g2 in pairs]
+  for (g1, g2), mx in zip(pairs, mixed):
+    n = (per_pair.get(int(m.geom_type[g2]), 1)
+         if m.geom_type[g1] == mdl.GEOM_PLANE else 1)
+    worst += n
+    worst_rows += n*(1 if mx['dim'] == 1 else 2*(mx['dim'] - 1))
+  nlimit = int(np.sum((np.asarray(m.jnt_limited) != 0) & np.isin(
+      m.jnt_type, (mdl.JNT_HINGE, mdl.JNT_SLIDE)))) if m.njnt else 0
+  if m.opt.disableflags & (mdl.DSBL_LIMIT | mdl.DSBL_CONSTRAINT):
+    nlimit = 0
+  if ncon_max is None:
+    ncon_max = min(worst, 32)
+  rows_per_con = max([1] + [1 if mx['dim'] == 1 else 2*(mx['dim'] - 1)
+                            for mx in mixed])
+  nefc_max = nlimit + min(worst_rows, ncon_max*rows_per_con)
+  return max(ncon_max, 1), max(nefc_max, 1)
+
+
+def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
+  """Returns the text of the constants header for model `m`."""
+  if m.opt.cone != mdl.CONE_PYRAMIDAL:
+    raise UnsupportedModelError('only pyramidal cones are implemented')
+  if m.opt.solver != mdl.SOLVER_NEWTON:
+    raise UnsupportedModelError('only the Newton solver is implemented')
+  pairs = collision_pairs(m)
+  mixed = [mix_pair(m, g1, g2) for g1, g2 in pairs]
+  ncon_max, nefc_max = capacities(m, pairs, ncon_max)
+  refsafe = not (m.opt.disableflags & mdl.DSBL_REFSAFE)
+  dt = float(m.opt.timestep)
+  if unroll is None:
+    unroll = m.nv <= 12 and m.nbody <= 10
+
+  limit_jnt = [j for j in range(m.njnt)
+               if m.jnt_limited[j] and m.jnt_type[j] in (mdl.JNT_HINGE,
+                                                         mdl.JNT_SLIDE)]
+  if m.opt.disableflags & (mdl.DSBL_LIMIT | mdl.DSBL_CONSTRAINT):
+    limit_jnt = []
+  limit_k, limit_b, limit_solimp = [], [], []
+  for j in limit_jnt:
+    k, b = _kb(m.jnt_solref[j], m.jnt_solimp[j], dt, refsafe)
+    limit_k.append(k)
+    limit_b.append(b)
+    limit_solimp.extend(_sanitise_solimp(m.jnt_solimp[j]))
+
+  pair_k, pair_b, pair_solimp, pair_diag, pair_fric = [], [], [], [], []
+  for (g1, g2), mx in zip(pairs, mixed):
+    k, b = _kb(mx['solref'], mx['solimp'], dt, refsafe)
+    pair_k.append(k)
+    pair_b.append(b)
+    pair_solimp.extend(_sanitise_solimp(mx['solimp']))
+    b1, b2 = int(m.geom_bodyid[g1]), int(m.geom_bodyid[g2])
+    tran = float(m.body_invweight0[b1, 0] + m.body_invweight0[b2, 0])
+    rot = float(m.body_invweight0[b1, 1] + m.body_invweight0[b2, 1])
+    fr = mx['friction']
+    # diagApprox: [frictionless/normal, pyramid edge k=1..5]
+    diag = [tran] + [tran + fr[k]*fr[k]*(tran if k < 2 else rot)
+                     for k in range(5)]
+    pair_diag.extend(diag)
+    pair_fric.extend(fr)
+
+  out = []
+  w = out.append
+  w('// GENERATED by dm_control_amd/codegen.py -- do not edit.')
+  w('// model %r  hash %s  task %d' % (getattr(m, 'modelname', ''),
+                                        m.content_hash(), task))
+  w('#pragma once')
+  w('#ifdef DMC_REAL_IS_DOUBLE')
+  w('typedef double dmc_real;')
+  w('#else')
+  w('typedef float dmc_real;')
+  w('#endif')
+  w('#define DMC_UNROLL %s' % ('_Pragma("unroll")' if unroll else ''))
+  w('namespace dmc_model {')
+
+  def ci(name, v):
+    w('constexpr int %s = %d;' % (name, int(v)))
+
+  def cd(name, v):
+    w('constexpr double %s = %r;' % (name, float(v)))
+
+  def ti(name, vals):
+    w('static __device__ constexpr int %s[] = {%s};' % (name, _fmt(vals, 'int')))
+
+  def tr(name, vals):
+    w('static __device__ constexpr dmc_real %s[] = {%s};'
+      % (name, _fmt(vals, 'real')))
+
+  ci('NQ', m.nq); ci('NV', m.nv); ci('NU', m.nu); ci('NBODY', m.nbody)
+  ci('NJNT', m.njnt); ci('NGEOM', m.ngeom); ci('NSENSOR', m.nsensor)
+  ci('NSENSORDATA', m.nsensordata)
+  ci('INTEGRATOR', m.opt.integrator); ci('DISABLEFLAGS', m.opt.disableflags)
+  ci('ITERATIONS', m.opt.iterations)
+  ci('NPAIR', len(pairs)); ci('NCON_MAX', ncon_max); ci('NEFC_MAX', nefc_max)
+  ci('NLIMIT', len(limit_jnt)); ci('TASK', task)
+  ci('NOBS', observation_size(m, task))
+  cd('timestep', dt); cd('tolerance_opt', m.opt.tolerance)
+  cd('meaninertia', m.meaninertia)
+  tr('gravity', m.opt.gravity)
+  tr('qpos0', m.qpos0); tr('qpos_spring', m.qpos_spring)
+  for name in ('body_parentid', 'body_rootid', 'body_jntnum', 'body_jntadr',
+               'body_dofnum', 'body_dofadr', 'jnt_type', 'jnt_qposadr',
+               'jnt_dofadr', 'jnt_bodyid', 'jnt_limited', 'dof_bodyid',
+               'dof_parentid', 'geom_type', 'geom_bodyid', 'actuator_trnid',
+               'actuator_ctrllimited', 'actuator_forcelimited',
+               'actuator_biastype', 'sensor_type', 'sensor_objid',
+               'sensor_adr'):
+    ti(name, getattr(m, name))
+  for name in ('body_pos', 'body_quat', 'body_ipos', 'body_iquat',
+               'body_mass', 'body_subtreemass', 'body_inertia', 'jnt_pos',
+               'jnt_axis', 'jnt_stiffness', 'jnt_range', 'jnt_margin',
+               'dof_armature', 'dof_damping', 'dof_invweight0', 'geom_size',
+               'geom_pos', 'geom_quat', 'geom_rbound', 'actuator_gear',
+               'actuator_ctrlrange', 'actuator_forcerange',
+               'actuator_gainprm', 'actuator_biasprm'):
+    tr(name, getattr(m, name))
+  ti('limit_jnt', limit_jnt)
+  tr('limit_K', limit_k); tr('limit_B', limit_b)
+  tr('limit_solimp', limit_solimp)
+  ti('pair_g1', [p[0] for p in pairs]); ti('pair_g2', [p[1] for p in pairs])
+  ti('pair_dim', [mx['dim'] for mx in mixed])
+  tr('pair_margin', [mx['margin'] for mx in mixed])
+  tr('pair_includemargin', [mx['includemargin'] for mx in mixed])
+  tr('pair_friction', pair_fric); tr('pair_K', pair_k); tr('pair_B', pair_b)
+  tr('pair_solimp', pair_solimp); tr('pair_diag', pair_diag)
+  ti('task_body', (task_bodies(m, task) + [0]*6)[:6])
+  w('}  // namespace dmc_model')
+  return '\n'.join(out) + '\n'
+
+
+def model_info(m, task=TASK_NONE, ncon_max=None):
+  """Sizes the host needs without loading the code object."""
+  pairs = collision_pairs(m)
+  ncon_max, nefc_max = capacities(m, pairs, ncon_max)
+  return dict(nq=m.nq, nv=m.nv, nu=m.nu, nbody=m.nbody,
+              nobs=observation_size(m, task), nsensordata=m.nsensordata,
+              ncon_max=ncon_max, nefc_max=nefc_max, npair=len(pairs),
+              ws_per_env=nefc_max*(m.nv + 4))

@@ -1,0 +1,1385 @@
+// dmc_kernels.hip -- batched MuJoCo-style physics step for gfx950 (MI355X).
+//
+// One code object is built per compiled model: the model constants arrive as
+// `static __device__ constexpr` tables in a generated header (-include'd by
+// the build, see dm_control_amd/codegen.py), so tree topology, geom pairs and
+// solver parameters are compile-time data for this translation unit.
+//
+// Replaces, for B independent environment instances per launch, the per-env
+// native calls of the reference:
+//   Physics.step        /root/reference/dm_control/mujoco/engine.py:149-166
+//   mj_step2 / mj_step / mj_step1 inside libmujoco
+//   task.get_observation / get_reward   suite/{cartpole,cheetah,humanoid}.py
+//
+// Layout: struct-of-arrays state field[k][env] in HBM; one environment per
+// lane, 64-lane workgroups (one wavefront each) so consecutive lanes read
+// consecutive addresses.  Constraint rows live in a per-launch HBM workspace
+// with the same [row*NV + dof][env] layout.  No MFMA: the largest dense object
+// is the NV x NV Hessian (81 entries for cheetah).
+//
+// `real` is float (default) or double (-DDMC_REAL_IS_DOUBLE) -- the fp64 build
+// is the tight-parity mode, the fp32 build is the throughput mode.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifdef DMC_REAL_IS_DOUBLE
+typedef double real;   // must match dmc_real in the generated header
+#define DMC_TOL_FLOOR 0.0
+#define DMC_MINVAL 1e-15
+#else
+typedef float real;
+// fp32 cannot resolve cost changes below ~1e-7 relative; see DESIGN.md
+#define DMC_TOL_FLOOR 1e-6
+#define DMC_MINVAL 1e-15f
+#endif
+
+#ifndef DMC_MODEL_HEADER
+#error "build with -DDMC_MODEL_HEADER=\"<generated model header>\" (dm_control_amd/codegen.py)"
+#endif
+#include DMC_MODEL_HEADER
+
+using namespace dmc_model;
+
+#define R(x) ((real)(x))
+#define DEV static __device__ __forceinline__
+#define DEVN static __device__ __noinline__
+
+constexpr int NM = NV*(NV + 1)/2;      // packed lower triangle
+constexpr int NVX = NV > 0 ? NV : 1;
+constexpr int NUX = NU > 0 ? NU : 1;
+constexpr real MAXVAL = R(1e10);
+
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_BOX = 6 };
+enum { DSBL_CONSTRAINT = 1 << 0, DSBL_LIMIT = 1 << 3, DSBL_CONTACT = 1 << 4,
+       DSBL_PASSIVE = 1 << 5, DSBL_GRAVITY = 1 << 6, DSBL_CLAMPCTRL = 1 << 7,
+       DSBL_WARMSTART = 1 << 8, DSBL_ACTUATION = 1 << 10 };
+// warn_mask bits follow mjtWarning order (engine.py:322-330)
+enum { WARN_INERTIA = 1, WARN_CONTACTFULL = 2, WARN_CNSTRFULL = 4,
+       WARN_BADQPOS = 16, WARN_BADQVEL = 32, WARN_BADQACC = 64,
+       WARN_BADCTRL = 128 };
+enum { TASK_NONE = 0, TASK_CARTPOLE = 1, TASK_CHEETAH = 2, TASK_HUMANOID = 3 };
+
+#define DMC_REALPTR real*
+#define DMC_CREALPTR const real*
+#include "dmc_args.h"
+
+// ---------------------------------------------------------------------------
+// math helpers
+// ---------------------------------------------------------------------------
+DEV real rsqrt_(real x) { return R(1)/sqrt(x); }
+DEV real dot3(const real* a, const real* b) {
+  return a[0]*b[0] + a[1]*b[1] + a[2]*b[2];
+}
+DEV void cross3(real* r, const real* a, const real* b) {
+  real x = a[1]*b[2] - a[2]*b[1], y = a[2]*b[0] - a[0]*b[2],
+       z = a[0]*b[1] - a[1]*b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+DEV real normalize3(real* a) {
+  real n = sqrt(dot3(a, a));
+  if (n < DMC_MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; }
+  else { real s = R(1)/n; a[0] *= s; a[1] *= s; a[2] *= s; }
+  return n;
+}
+DEV void normalize4(real* q) {
+  real n = sqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+  if (n < DMC_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+  else { real s = R(1)/n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
+}
+DEV void mulquat(real* r, const real* a, const real* b) {
+  real w = a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3];
+  real x = a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2];
+  real y = a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1];
+  real z = a[0]*b[3] + a[1]*b[2] - a[2]*b[1] + a[3]*b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+DEV void quat2mat(real* m, const real* q) {
+  real w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = w*w + x*x - y*y - z*z; m[1] = 2*(x*y - w*z); m[2] = 2*(x*z + w*y);
+  m[3] = 2*(x*y + w*z); m[4] = w*w - x*x + y*y - z*z; m[5] = 2*(y*z - w*x);
+  m[6] = 2*(x*z - w*y); m[7] = 2*(y*z + w*x); m[8] = w*w - x*x - y*y + z*z;
+}
+DEV void mulmatvec3(real* r, const real* m, const real* v) {
+  real x = m[0]*v[0] + m[1]*v[1] + m[2]*v[2];
+  real y = m[3]*v[0] + m[4]*v[1] + m[5]*v[2];
+  real z = m[6]*v[0] + m[7]*v[1] + m[8]*v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+DEV void rotvecquat(real* r, const real* v, const real* q) {
+  real m[9];
+  quat2mat(m, q);
+  mulmatvec3(r, m, v);
+}
+DEV void axisangle2quat(real* q, const real* axis, real angle) {
+  real s, c;
+#ifdef DMC_REAL_IS_DOUBLE
+  sincos(angle*R(0.5), &s, &c);
+#else
+  sincosf(angle*R(0.5), &s, &c);
+#endif
+  q[0] = c; q[1] = axis[0]*s; q[2] = axis[1]*s; q[3] = axis[2]*s;
+}
+DEV void quat_integrate(real* q, const real* w, real h) {
+  real ax[3] = {w[0], w[1], w[2]};
+  real n = normalize3(ax);
+  if (n < DMC_MINVAL) return;
+  real dq[4], r[4];
+  axisangle2quat(dq, ax, h*n);
+  mulquat(r, q, dq);
+  normalize4(r);
+  q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = r[3];
+}
+DEV real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+DEV bool bad(real x) { return !(x <= MAXVAL && x >= -MAXVAL); }
+
+// spatial vectors [angular, linear] about the subtree-root centre of mass
+DEV void cross_motion(real* r, const real* v, const real* s) {
+  real a[3], b[3], c[3];
+  cross3(a, v, s); cross3(b, v, s + 3); cross3(c, v + 3, s);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+  r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+DEV void cross_force(real* r, const real* v, const real* f) {
+  real a[3], b[3], c[3];
+  cross3(a, v, f); cross3(b, v + 3, f + 3); cross3(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+DEV void mul_inert_vec(real* r, const real* i, const real* v) {
+  r[0] = i[0]*v[0] + i[3]*v[1] + i[4]*v[2] - i[8]*v[4] + i[7]*v[5];
+  r[1] = i[3]*v[0] + i[1]*v[1] + i[5]*v[2] + i[8]*v[3] - i[6]*v[5];
+  r[2] = i[4]*v[0] + i[5]*v[1] + i[2]*v[2] - i[7]*v[3] + i[6]*v[4];
+  r[3] = i[8]*v[1] - i[7]*v[2] + i[9]*v[3];
+  r[4] = i[6]*v[2] - i[8]*v[0] + i[9]*v[4];
+  r[5] = i[7]*v[0] - i[6]*v[1] + i[9]*v[5];
+}
+DEV real dot6(const real* a, const real* b) {
+  return a[0]*b[0] + a[1]*b[1] + a[2]*b[2] + a[3]*b[3] + a[4]*b[4] + a[5]*b[5];
+}
+DEV int tri(int i, int j) { return i*(i + 1)/2 + j; }   // i >= j
+
+// y = A x for packed symmetric A
+DEV void symv(real* y, const real* A, const real* x) {
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) {
+    real s = 0;
+    DMC_UNROLL
+    for (int j = 0; j < NV; j++) s += A[i >= j ? tri(i, j) : tri(j, i)]*x[j];
+    y[i] = s;
+  }
+}
+// in-place packed Cholesky A = L L^T; returns number of clamped pivots
+DEV int chol_factor(real* A) {
+  int nbad = 0;
+  DMC_UNROLL
+  for (int j = 0; j < NV; j++) {
+    real s = A[tri(j, j)];
+    DMC_UNROLL
+    for (int k = 0; k < j; k++) s -= A[tri(j, k)]*A[tri(j, k)];
+    if (!(s >= DMC_MINVAL)) { s = DMC_MINVAL; nbad++; }
+    real inv = rsqrt_(s);
+    A[tri(j, j)] = s*inv;
+    DMC_UNROLL
+    for (int i = j + 1; i < NV; i++) {
+      real t = A[tri(i, j)];
+      DMC_UNROLL
+      for (int k = 0; k < j; k++) t -= A[tri(i, k)]*A[tri(j, k)];
+      A[tri(i, j)] = t*inv;
+    }
+  }
+  return nbad;
+}
+DEV void chol_solve(real* x, const real* L) {
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) {
+    real s = x[i];
+    DMC_UNROLL
+    for (int k = 0; k < i; k++) s -= L[tri(i, k)]*x[k];
+    x[i] = s/L[tri(i, i)];
+  }
+  DMC_UNROLL
+  for (int i = NV - 1; i >= 0; i--) {
+    real s = x[i];
+    DMC_UNROLL
+    for (int k = i + 1; k < NV; k++) s -= L[tri(k, i)]*x[k];
+    x[i] = s/L[tri(i, i)];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// per-lane working set of one environment
+// ---------------------------------------------------------------------------
+struct Env {
+  real qpos[NQ > 0 ? NQ : 1], qvel[NVX], ctrl[NUX], warm[NVX];
+  real xpos[NBODY*3], xquat[NBODY*4], xmat[NBODY*9];
+  real xipos[NBODY*3], ximat[NBODY*9];
+  real xanchor[(NJNT > 0 ? NJNT : 1)*3], xaxis[(NJNT > 0 ? NJNT : 1)*3];
+  real subtree_com[NBODY*3];
+  real cinert[NBODY*10];
+  real cdof[NVX*6], cdof_dot[NVX*6], cvel[NBODY*6];
+  real qM[NM > 0 ? NM : 1], qL[NM > 0 ? NM : 1];
+  real qfrc_smooth[NVX], qfrc_constraint[NVX], qacc_smooth[NVX], qacc[NVX];
+  real subtree_linvel[NBODY*3];
+  int ncon, nefc, iters;
+  unsigned warn;
+};
+
+struct Work {
+  real* base; long long nenv; int e;
+  __device__ real& J(int r, int j) const { return base[((long long)(r*NV + j))*nenv + e]; }
+  __device__ real& D(int r) const { return base[((long long)(NEFC_MAX*NV + r))*nenv + e]; }
+  __device__ real& aref(int r) const { return base[((long long)(NEFC_MAX*NV + NEFC_MAX + r))*nenv + e]; }
+  __device__ real& jar(int r) const { return base[((long long)(NEFC_MAX*NV + 2*NEFC_MAX + r))*nenv + e]; }
+  __device__ real& jv(int r) const { return base[((long long)(NEFC_MAX*NV + 3*NEFC_MAX + r))*nenv + e]; }
+};
+
+// ---------------------------------------------------------------------------
+// position stage: kinematics, centre-of-mass frame, composite inertia
+// ---------------------------------------------------------------------------
+DEV void kinematics(Env& E) {
+  E.xpos[0] = E.xpos[1] = E.xpos[2] = 0;
+  E.xquat[0] = 1; E.xquat[1] = E.xquat[2] = E.xquat[3] = 0;
+  quat2mat(E.xmat, E.xquat);
+  for (int k = 0; k < 3; k++) E.xipos[k] = 0;
+  for (int k = 0; k < 9; k++) E.ximat[k] = E.xmat[k];
+  DMC_UNROLL
+  for (int i = 1; i < NBODY; i++) {
+    real xpos[3], xquat[4];
+    const int jadr = body_jntadr[i], jnum = body_jntnum[i];
+    if (jnum == 1 && jnt_type[jadr < 0 ? 0 : jadr] == JNT_FREE) {
+      const int qa = jnt_qposadr[jadr];
+      for (int k = 0; k < 3; k++) xpos[k] = E.qpos[qa + k];
+      for (int k = 0; k < 4; k++) xquat[k] = E.qpos[qa + 3 + k];
+      normalize4(xquat);
+      for (int k = 0; k < 3; k++) {
+        E.xanchor[3*jadr + k] = xpos[k];
+        E.xaxis[3*jadr + k] = R(jnt_axis[3*jadr + k]);
+      }
+    } else {
+      const int pid = body_parentid[i];
+      real bp[3] = {R(body_pos[3*i]), R(body_pos[3*i + 1]), R(body_pos[3*i + 2])};
+      real bq[4] = {R(body_quat[4*i]), R(body_quat[4*i + 1]),
+                    R(body_quat[4*i + 2]), R(body_quat[4*i + 3])};
+      real v[3];
+      mulmatvec3(v, E.xmat + 9*pid, bp);
+      for (int k = 0; k < 3; k++) xpos[k] = E.xpos[3*pid + k] + v[k];
+      mulquat(xquat, E.xquat + 4*pid, bq);
+      for (int j = 0; j < jnum; j++) {
+        const int jid = jadr + j, qa = jnt_qposadr[jid];
+        real jax[3] = {R(jnt_axis[3*jid]), R(jnt_axis[3*jid + 1]), R(jnt_axis[3*jid + 2])};
+        real jp[3] = {R(jnt_pos[3*jid]), R(jnt_pos[3*jid + 1]), R(jnt_pos[3*jid + 2])};
+        real* anchor = E.xanchor + 3*jid;
+        real* axis = E.xaxis + 3*jid;
+        rotvecquat(axis, jax, xquat);
+        rotvecquat(anchor, jp, xquat);
+        for (int k = 0; k < 3; k++) anchor[k] += xpos[k];
+        if (jnt_type[jid] == JNT_SLIDE) {
+          real q = E.qpos[qa] - R(qpos0[qa]);
+          for (int k = 0; k < 3; k++) xpos[k] += axis[k]*q;
+        } else if (jnt_type[jid] == JNT_HINGE || jnt_type[jid] == JNT_BALL) {
+          real qloc[4], r[4], vec[3];
+          if (jnt_type[jid] == JNT_BALL) {
+            for (int k = 0; k < 4; k++) qloc[k] = E.qpos[qa + k];
+            normalize4(qloc);
+          } else {
+            axisangle2quat(qloc, jax, E.qpos[qa] - R(qpos0[qa]));
+          }
+          mulquat(r, xquat, qloc);
+          for (int k = 0; k < 4; k++) xquat[k] = r[k];
+          rotvecquat(vec, jp, xquat);
+          for (int k = 0; k < 3; k++) xpos[k] = anchor[k] - vec[k];
+        }
+      }
+    }
+    normalize4(xquat);
+    for (int k = 0; k < 3; k++) E.xpos[3*i + k] = xpos[k];
+    for (int k = 0; k < 4; k++) E.xquat[4*i + k] = xquat[k];
+    quat2mat(E.xmat + 9*i, xquat);
+    // inertial frame
+    real ip[3] = {R(body_ipos[3*i]), R(body_ipos[3*i + 1]), R(body_ipos[3*i + 2])};
+    real iq[4] = {R(body_iquat[4*i]), R(body_iquat[4*i + 1]),
+                  R(body_iquat[4*i + 2]), R(body_iquat[4*i + 3])};
+    real v[3], q[4];
+    mulmatvec3(v, E.xmat + 9*i, ip);
+    for (int k = 0; k < 3; k++) E.xipos[3*i + k] = xpos[k] + v[k];
+    mulquat(q, xquat, iq);
+    quat2mat(E.ximat + 9*i, q);
+  }
+}
+
+DEV void com_pos(Env& E) {
+  DMC_UNROLL
+  for (int i = 0; i < NBODY; i++)
+    for (int k = 0; k < 3; k++)
+      E.subtree_com[3*i + k] = R(body_mass[i])*E.xipos[3*i + k];
+  DMC_UNROLL
+  for (int i = NBODY - 1; i > 0; i--)
+    for (int k = 0; k < 3; k++)
+      E.subtree_com[3*body_parentid[i] + k] += E.subtree_com[3*i + k];
+  DMC_UNROLL
+  for (int i = 0; i < NBODY; i++) {
+    if (body_subtreemass[i] < 1e-15) {
+      for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] = E.xipos[3*i + k];
+    } else {
+      real inv = R(1.0/(body_subtreemass[i] < 1e-15 ? 1.0 : body_subtreemass[i]));
+      for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] *= inv;
+    }
+  }
+  for (int k = 0; k < 10; k++) E.cinert[k] = 0;
+  DMC_UNROLL
+  for (int i = 1; i < NBODY; i++) {
+    const real* com = E.subtree_com + 3*body_rootid[i];
+    const real* mat = E.ximat + 9*i;
+    real dif[3], t[9];
+    const real mass = R(body_mass[i]);
+    const real in0 = R(body_inertia[3*i]), in1 = R(body_inertia[3*i + 1]),
+               in2 = R(body_inertia[3*i + 2]);
+    for (int k = 0; k < 3; k++) dif[k] = E.xipos[3*i + k] - com[k];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++)
+        t[3*a + b] = mat[3*a]*in0*mat[3*b] + mat[3*a + 1]*in1*mat[3*b + 1] +
+                     mat[3*a + 2]*in2*mat[3*b + 2];
+    real* res = E.cinert + 10*i;
+    res[0] = t[0] + mass*(dif[1]*dif[1] + dif[2]*dif[2]);
+    res[1] = t[4] + mass*(dif[0]*dif[0] + dif[2]*dif[2]);
+    res[2] = t[8] + mass*(dif[0]*dif[0] + dif[1]*dif[1]);
+    res[3] = t[1] - mass*dif[0]*dif[1];
+    res[4] = t[2] - mass*dif[0]*dif[2];
+    res[5] = t[5] - mass*dif[1]*dif[2];
+    res[6] = mass*dif[0]; res[7] = mass*dif[1]; res[8] = mass*dif[2];
+    res[9] = mass;
+  }
+  DMC_UNROLL
+  for (int j = 0; j < NJNT; j++) {
+    const int b = jnt_bodyid[j], da = jnt_dofadr[j];
+    const real* com = E.subtree_com + 3*body_rootid[b];
+    real off[3];
+    for (int k = 0; k < 3; k++) off[k] = com[k] - E.xanchor[3*j + k];
+    real* cd = E.cdof + 6*da;
+    if (jnt_type[j] == JNT_FREE || jnt_type[j] == JNT_BALL) {
+      if (jnt_type[j] == JNT_FREE) {
+        for (int k = 0; k < 18; k++) cd[k] = 0;
+        cd[3] = 1; cd[6 + 4] = 1; cd[12 + 5] = 1;
+        cd += 18;
+      }
+      for (int k = 0; k < 3; k++) {
+        real ax[3] = {E.xmat[9*b + k], E.xmat[9*b + 3 + k], E.xmat[9*b + 6 + k]};
+        for (int c = 0; c < 3; c++) cd[6*k + c] = ax[c];
+        cross3(cd + 6*k + 3, ax, off);
+      }
+    } else if (jnt_type[j] == JNT_SLIDE) {
+      cd[0] = cd[1] = cd[2] = 0;
+      for (int k = 0; k < 3; k++) cd[3 + k] = E.xaxis[3*j + k];
+    } else {
+      for (int k = 0; k < 3; k++) cd[k] = E.xaxis[3*j + k];
+      cross3(cd + 3, E.xaxis + 3*j, off);
+    }
+  }
+}
+
+// composite rigid body algorithm -> packed M, then M = L L^T
+DEV void crb_factor(Env& E) {
+  real crb[NBODY*10];
+  DMC_UNROLL
+  for (int i = 0; i < NBODY*10; i++) crb[i] = E.cinert[i];
+  DMC_UNROLL
+  for (int i = NBODY - 1; i > 0; i--)
+    if (body_parentid[i] > 0)
+      for (int k = 0; k < 10; k++) crb[10*body_parentid[i] + k] += crb[10*i + k];
+  DMC_UNROLL
+  for (int i = 0; i < NM; i++) E.qM[i] = 0;
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) {
+    real buf[6];
+    mul_inert_vec(buf, crb + 10*dof_bodyid[i], E.cdof + 6*i);
+    E.qM[tri(i, i)] = dot6(E.cdof + 6*i, buf) + R(dof_armature[i]);
+    for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j])
+      E.qM[tri(i, j)] = dot6(E.cdof + 6*j, buf);
+  }
+  DMC_UNROLL
+  for (int i = 0; i < NM; i++) E.qL[i] = E.qM[i];
+  if (chol_factor(E.qL)) E.warn |= WARN_INERTIA;
+}
+
+// ---------------------------------------------------------------------------
+// velocity stage: body velocities, passive forces, RNE bias
+// ---------------------------------------------------------------------------
+DEV void com_vel(Env& E) {
+  for (int k = 0; k < 6; k++) E.cvel[k] = 0;
+  DMC_UNROLL
+  for (int i = 1; i < NBODY; i++) {
+    real cvel[6];
+    for (int k = 0; k < 6; k++) cvel[k] = E.cvel[6*body_parentid[i] + k];
+    const int jadr = body_jntadr[i];
+    for (int j = 0; j < body_jntnum[i]; j++) {
+      const int jid = jadr + j;
+      int da = jnt_dofadr[jid];
+      if (jnt_type[jid] == JNT_FREE || jnt_type[jid] == JNT_BALL) {
+        if (jnt_type[jid] == JNT_FREE) {
+          for (int k = 0; k < 18; k++) E.cdof_dot[6*da + k] = 0;
+          for (int k = 0; k < 3; k++)
+            for (int c = 0; c < 6; c++)
+              cvel[c] += E.cdof[6*(da + k) + c]*E.qvel[da + k];
+          da += 3;
+        }
+        for (int k = 0; k < 3; k++)
+          cross_motion(E.cdof_dot + 6*(da + k), cvel, E.cdof + 6*(da + k));
+        for (int k = 0; k < 3; k++)
+          for (int c = 0; c < 6; c++)
+            cvel[c] += E.cdof[6*(da + k) + c]*E.qvel[da + k];
+      } else {
+        cross_motion(E.cdof_dot + 6*da, cvel, E.cdof + 6*da);
+        for (int c = 0; c < 6; c++) cvel[c] += E.cdof[6*da + c]*E.qvel[da];
+      }
+    }
+    for (int k = 0; k < 6; k++) E.cvel[6*i + k] = cvel[k];
+  }
+}
+
+// qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
+DEV void smooth_forces(Env& E, bool actuation) {
+  real cacc[NBODY*6], cfrc[NBODY*6];
+  for (int k = 0; k < 6; k++) { cacc[k] = 0; cfrc[k] = 0; }
+  if (!(DISABLEFLAGS & DSBL_GRAVITY))
+    for (int k = 0; k < 3; k++) cacc[3 + k] = -R(gravity[k]);
+  DMC_UNROLL
+  for (int i = 1; i < NBODY; i++) {
+    real tmp[6], tmp1[6];
+    const int da = body_dofadr[i];
+    for (int k = 0; k < 6; k++) cacc[6*i + k] = cacc[6*body_parentid[i] + k];
+    for (int j = 0; j < body_dofnum[i]; j++)
+      for (int k = 0; k < 6; k++)
+        cacc[6*i + k] += E.cdof_dot[6*(da + j) + k]*E.qvel[da + j];
+    mul_inert_vec(cfrc + 6*i, E.cinert + 10*i, cacc + 6*i);
+    mul_inert_vec(tmp, E.cinert + 10*i, E.cvel + 6*i);
+    cross_force(tmp1, E.cvel + 6*i, tmp);
+    for (int k = 0; k < 6; k++) cfrc[6*i + k] += tmp1[k];
+  }
+  DMC_UNROLL
+  for (int i = NBODY - 1; i > 0; i--)
+    if (body_parentid[i] > 0)
+      for (int k = 0; k < 6; k++) cfrc[6*body_parentid[i] + k] += cfrc[6*i + k];
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++)
+    E.qfrc_smooth[i] = -dot6(E.cdof + 6*i, cfrc + 6*dof_bodyid[i]);
+  if (!(DISABLEFLAGS & DSBL_PASSIVE)) {
+    DMC_UNROLL
+    for (int j = 0; j < NJNT; j++)
+      if (jnt_stiffness[j] != 0 &&
+          (jnt_type[j] == JNT_SLIDE || jnt_type[j] == JNT_HINGE)) {
+        const int qa = jnt_qposadr[j];
+        E.qfrc_smooth[jnt_dofadr[j]] -=
+            R(jnt_stiffness[j])*(E.qpos[qa] - R(qpos_spring[qa]));
+      }
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++)
+      E.qfrc_smooth[i] -= R(dof_damping[i])*E.qvel[i];
+  }
+  if (actuation && !(DISABLEFLAGS & DSBL_ACTUATION)) {
+    DMC_UNROLL
+    for (int i = 0; i < NU; i++) {
+      const int j = actuator_trnid[i], dof = jnt_dofadr[j];
+      const real gear = R(actuator_gear[i]);
+      real c = E.ctrl[i];
+      if (actuator_ctrllimited[i] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
+        c = clampr(c, R(actuator_ctrlrange[2*i]), R(actuator_ctrlrange[2*i + 1]));
+      real force = R(actuator_gainprm[3*i])*c;
+      if (actuator_biastype[i] == 1)
+        force += R(actuator_biasprm[3*i]) +
+                 R(actuator_biasprm[3*i + 1])*gear*E.qpos[jnt_qposadr[j]] +
+                 R(actuator_biasprm[3*i + 2])*gear*E.qvel[dof];
+      if (actuator_forcelimited[i])
+        force = clampr(force, R(actuator_forcerange[2*i]), R(actuator_forcerange[2*i + 1]));
+      E.qfrc_smooth[dof] += gear*force;
+    }
+  }
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) E.qacc_smooth[i] = E.qfrc_smooth[i];
+  chol_solve(E.qacc_smooth, E.qL);
+}
+
+DEV void subtree_vel(Env& E) {
+  DMC_UNROLL
+  for (int i = 0; i < NBODY; i++) {
+    real dif[3], t[3];
+    const real* com = E.subtree_com + 3*body_rootid[i];
+    for (int k = 0; k < 3; k++) dif[k] = E.xipos[3*i + k] - com[k];
+    cross3(t, E.cvel + 6*i, dif);
+    for (int k = 0; k < 3; k++)
+      E.subtree_linvel[3*i + k] = R(body_mass[i])*(E.cvel[6*i + 3 + k] + t[k]);
+  }
+  DMC_UNROLL
+  for (int i = NBODY - 1; i > 0; i--)
+    for (int k = 0; k < 3; k++)
+      E.subtree_linvel[3*body_parentid[i] + k] += E.subtree_linvel[3*i + k];
+  DMC_UNROLL
+  for (int i = 0; i < NBODY; i++) {
+    real inv = R(1.0/(body_subtreemass[i] < 1e-15 ? 1e-15 : body_subtreemass[i]));
+    for (int k = 0; k < 3; k++) E.subtree_linvel[3*i + k] *= inv;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// constraints: joint limits + contacts -> rows in the HBM workspace
+// ---------------------------------------------------------------------------
+DEV real impedance(const real* s, real x) {
+  // s = sanitised (d0, dmax, width, midpoint, power), generated by the host
+  const real d0 = R(s[0]), d1 = R(s[1]), width = R(s[2]), mid = R(s[3]),
+             power = R(s[4]);
+  if (s[0] == s[1] || s[2] <= R(1e-15)) return R(0.5)*(d0 + d1);
+  x = fabs(x)/width;
+  if (x >= 1) return d1;
+  if (x <= 0) return d0;
+  real y;
+  if (s[4] == R(1)) y = x;
+  else if (s[4] == R(2)) y = x <= mid ? x*x/mid : 1 - (1 - x)*(1 - x)/(1 - mid);
+  else if (x <= mid) y = pow(x, power)/pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power)/pow(1 - mid, power - 1);
+  return d0 + y*(d1 - d0);
+}
+
+// row[j] += sign * dir . d(point velocity)/d(qvel_j) for a point on `body`
+DEV void add_jac_dir(real* row, const Env& E, int body, const real* point,
+                     const real* dir, real sign) {
+  while (body > 0 && body_dofnum[body] == 0) body = body_parentid[body];
+  if (body <= 0) return;
+  real off[3], w[3];
+  const int root = body_rootid[body];
+  for (int k = 0; k < 3; k++) off[k] = point[k] - E.subtree_com[3*root + k];
+  cross3(w, off, dir);   // dir.(ang x off) = ang.(off x dir)
+  for (int i = body_dofadr[body] + body_dofnum[body] - 1; i >= 0; i = dof_parentid[i]) {
+    const real* cd = E.cdof + 6*i;
+    row[i] += sign*(dot3(dir, cd + 3) + dot3(w, cd));
+  }
+}
+DEV void add_jac_rot(real* row, const Env& E, int body, const real* dir, real sign) {
+  while (body > 0 && body_dofnum[body] == 0) body = body_parentid[body];
+  if (body <= 0) return;
+  for (int i = body_dofadr[body] + body_dofnum[body] - 1; i >= 0; i = dof_parentid[i])
+    row[i] += sign*dot3(dir, E.cdof + 6*i);
+}
+
+DEV bool push_row(Env& E, const Work& W, const real* row, real pos_minus_margin,
+                  real K, real B, real imp, real Rrow) {
+  if (E.nefc >= NEFC_MAX) { E.warn |= WARN_CNSTRFULL; return false; }
+  const int r = E.nefc++;
+  real vel = 0;
+  DMC_UNROLL
+  for (int j = 0; j < NV; j++) { W.J(r, j) = row[j]; vel += row[j]*E.qvel[j]; }
+  W.aref(r) = -B*vel - K*imp*pos_minus_margin;
+  W.D(r) = R(1)/(Rrow < DMC_MINVAL ? DMC_MINVAL : Rrow);
+  return true;
+}
+
+DEV void limit_rows(Env& E, const Work& W) {
+  if (DISABLEFLAGS & (DSBL_LIMIT | DSBL_CONSTRAINT)) return;
+  DMC_UNROLL
+  for (int l = 0; l < NLIMIT; l++) {
+    const int j = limit_jnt[l], qa = jnt_qposadr[j], dof = jnt_dofadr[j];
+    const real margin = R(jnt_margin[j]);
+    const real q = E.qpos[qa];
+    for (int side = -1; side <= 1; side += 2) {
+      const real dist = side < 0 ? q - R(jnt_range[2*j]) : R(jnt_range[2*j + 1]) - q;
+      if (dist < margin) {
+        real row[NVX];
+        DMC_UNROLL
+        for (int k = 0; k < NV; k++) row[k] = 0;
+        row[dof] = -(real)side;
+        const real pm = dist - margin;
+        const real imp = impedance(limit_solimp + 5*l, pm);
+        const real Rr = (1 - imp)*R(dof_invweight0[dof])/imp;
+        push_row(E, W, row, pm, R(limit_K[l]), R(limit_B[l]), imp, Rr);
+      }
+    }
+  }
+}
+
+struct RawCon { real dist, pos[3], frame[6]; };   // frame: normal, tangent hint
+
+DEV void make_frame(const real* fin, real* f) {   // f[9]
+  for (int k = 0; k < 6; k++) f[k] = fin[k];
+  normalize3(f);
+  if (sqrt(dot3(f + 3, f + 3)) < R(0.5)) {
+    f[3] = f[4] = f[5] = 0;
+    if (f[1] < R(0.5) && f[1] > R(-0.5)) f[4] = 1; else f[5] = 1;
+  }
+  real t = dot3(f, f + 3);
+  for (int k = 0; k < 3; k++) f[3 + k] -= t*f[k];
+  normalize3(f + 3);
+  cross3(f + 6, f, f + 3);
+}
+
+DEV int plane_sphere(RawCon* c, real margin, const real* ppos, const real* pn,
+                     const real* spos, real r) {
+  real dif[3];
+  for (int k = 0; k < 3; k++) dif[k] = spos[k] - ppos[k];
+  const real dist = dot3(dif, pn) - r;
+  if (dist > margin) return 0;
+  c->dist = dist;
+  for (int k = 0; k < 3; k++) {
+    c->pos[k] = spos[k] - pn[k]*(r + R(0.5)*dist);
+    c->frame[k] = pn[k]; c->frame[3 + k] = 0;
+  }
+  return 1;
+}
+DEV int sphere_sphere(RawCon* c, real margin, const real* p1, const real* p2,
+                      real r1, real r2) {
+  real dif[3];
+  for (int k = 0; k < 3; k++) dif[k] = p2[k] - p1[k];
+  const real len = sqrt(dot3(dif, dif));
+  const real dist = len - r1 - r2;
+  if (dist > margin) return 0;
+  c->dist = dist;
+  if (len < DMC_MINVAL) { c->frame[0] = 1; c->frame[1] = c->frame[2] = 0; }
+  else for (int k = 0; k < 3; k++) c->frame[k] = dif[k]/len;
+  for (int k = 0; k < 3; k++) {
+    c->pos[k] = p1[k] + c->frame[k]*(r1 + R(0.5)*dist);
+    c->frame[3 + k] = 0;
+  }
+  return 1;
+}
+
+// geom world pose on demand (body pose x local offset)
+DEV void geom_pose(const Env& E, int g, real* pos, real* mat) {
+  const int b = geom_bodyid[g];
+  real gp[3] = {R(geom_pos[3*g]), R(geom_pos[3*g + 1]), R(geom_pos[3*g + 2])};
+  real gq[4] = {R(geom_quat[4*g]), R(geom_quat[4*g + 1]), R(geom_quat[4*g + 2]),
+                R(geom_quat[4*g + 3])};
+  real v[3], q[4];
+  mulmatvec3(v, E.xmat + 9*b, gp);
+  for (int k = 0; k < 3; k++) pos[k] = E.xpos[3*b + k] + v[k];
+  mulquat(q, E.xquat + 4*b, gq);
+  normalize4(q);
+  quat2mat(mat, q);
+}
+
+DEV int collide_pair(const Env& E, int p, RawCon* rc) {
+  const int g1 = pair_g1[p], g2 = pair_g2[p];
+  const int t1 = geom_type[g1], t2 = geom_type[g2];
+  const real margin = R(pair_margin[p]);
+  real p1[3], m1[9], p2[3], m2[9];
+  geom_pose(E, g1, p1, m1);
+  geom_pose(E, g2, p2, m2);
+  const real s1[3] = {R(geom_size[3*g1]), R(geom_size[3*g1 + 1]), R(geom_size[3*g1 + 2])};
+  const real s2[3] = {R(geom_size[3*g2]), R(geom_size[3*g2 + 1]), R(geom_size[3*g2 + 2])};
+  real dif[3];
+  for (int k = 0; k < 3; k++) dif[k] = p2[k] - p1[k];
+  if (t1 == GEOM_PLANE) {
+    const real n[3] = {m1[2], m1[5], m1[8]};
+    if (dot3(dif, n) > R(geom_rbound[g2]) + margin) return 0;
+    if (t2 == GEOM_SPHERE) return plane_sphere(rc, margin, p1, n, p2, s2[0]);
+    if (t2 == GEOM_CAPSULE) {
+      const real ax[3] = {m2[2], m2[5], m2[8]};
+      real q[3];
+      int cnt = 0;
+      for (int k = 0; k < 3; k++) q[k] = p2[k] + ax[k]*s2[1];
+      int c1 = plane_sphere(rc, margin, p1, n, q, s2[0]);
+      if (c1) for (int k = 0; k < 3; k++) rc[0].frame[3 + k] = ax[k];
+      cnt += c1;
+      for (int k = 0; k < 3; k++) q[k] = p2[k] - ax[k]*s2[1];
+      c1 = plane_sphere(rc + cnt, margin, p1, n, q, s2[0]);
+      if (c1) for (int k = 0; k < 3; k++) rc[cnt].frame[3 + k] = ax[k];
+      return cnt + c1;
+    }
+    if (t2 == GEOM_BOX) {
+      const real dist = dot3(dif, n);
+      int cnt = 0;
+      for (int i = 0; i < 8; i++) {
+        real v[3] = {(i & 1) ? s2[0] : -s2[0], (i & 2) ? s2[1] : -s2[1],
+                     (i & 4) ? s2[2] : -s2[2]};
+        real corner[3];
+        mulmatvec3(corner, m2, v);
+        const real ld = dot3(n, corner);
+        if (dist + ld > margin || ld > 0 || cnt >= 4) continue;
+        rc[cnt].dist = dist + ld;
+        for (int k = 0; k < 3; k++) {
+          rc[cnt].pos[k] = corner[k] + p2[k] - n[k]*R(0.5)*(dist + ld);
+          rc[cnt].frame[k] = n[k]; rc[cnt].frame[3 + k] = 0;
+        }
+        cnt++;
+      }
+      return cnt;
+    }
+    return 0;
+  }
+  {
+    const real bound = R(geom_rbound[g1]) + R(geom_rbound[g2]) + margin;
+    if (dot3(dif, dif) > bound*bound) return 0;
+  }
+  if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE)
+    return sphere_sphere(rc, margin, p1, p2, s1[0], s2[0]);
+  if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) {
+    const real ax[3] = {m2[2], m2[5], m2[8]};
+    real v[3], q[3];
+    for (int k = 0; k < 3; k++) v[k] = p1[k] - p2[k];
+    const real x = clampr(dot3(ax, v), -s2[1], s2[1]);
+    for (int k = 0; k < 3; k++) q[k] = p2[k] + ax[k]*x;
+    return sphere_sphere(rc, margin, p1, q, s1[0], s2[0]);
+  }
+  if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) {
+    real a1[3], a2[3], d[3], v1[3], v2[3];
+    for (int k = 0; k < 3; k++) {
+      a1[k] = m1[3*k + 2]*s1[1]; a2[k] = m2[3*k + 2]*s2[1]; d[k] = p1[k] - p2[k];
+    }
+    const real ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2);
+    const real u = -dot3(a1, d), v = dot3(a2, d);
+    const real det = ma*mc - mb*mb;
+    if (fabs(det) >= DMC_MINVAL) {
+      real x1 = (mc*u - mb*v)/det, x2 = (ma*v - mb*u)/det;
+      if (x1 > 1) { x1 = 1; x2 = (v - mb)/mc; }
+      else if (x1 < -1) { x1 = -1; x2 = (v + mb)/mc; }
+      if (x2 > 1) { x2 = 1; x1 = clampr((u - mb)/ma, -1, 1); }
+      else if (x2 < -1) { x2 = -1; x1 = clampr((u + mb)/ma, -1, 1); }
+      for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
+      return sphere_sphere(rc, margin, v1, v2, s1[0], s2[0]);
+    }
+    int n = 0;
+    real x;
+    for (int k = 0; k < 3; k++) v1[k] = p1[k] + a1[k];
+    x = clampr((v - mb)/mc, -1, 1);
+    for (int k = 0; k < 3; k++) v2[k] = p2[k] + a2[k]*x;
+    n += sphere_sphere(rc + n, margin, v1, v2, s1[0], s2[0]);
+    for (int k = 0; k < 3; k++) v1[k] = p1[k] - a1[k];
+    x = clampr((v + mb)/mc, -1, 1);
+    for (int k = 0; k < 3; k++) v2[k] = p2[k] + a2[k]*x;
+    n += sphere_sphere(rc + n, margin, v1, v2, s1[0], s2[0]);
+    if (n == 2) return n;
+    for (int k = 0; k < 3; k++) v2[k] = p2[k] + a2[k];
+    x = clampr((u - mb)/ma, -1, 1);
+    for (int k = 0; k < 3; k++) v1[k] = p1[k] + a1[k]*x;
+    n += sphere_sphere(rc + n, margin, v1, v2, s1[0], s2[0]);
+    if (n == 2) return n;
+    for (int k = 0; k < 3; k++) v2[k] = p2[k] - a2[k];
+    x = clampr((u + mb)/ma, -1, 1);
+    for (int k = 0; k < 3; k++) v1[k] = p1[k] + a1[k]*x;
+    n += sphere_sphere(rc + n, margin, v1, v2, s1[0], s2[0]);
+    return n;
+  }
+  return 0;
+}
+
+DEVN void contact_rows(Env& E, const Work& W) {
+  if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return;
+  for (int p = 0; p < NPAIR; p++) {
+    RawCon rc[4];
+    const int n = collide_pair(E, p, rc);
+    for (int c = 0; c < n; c++) {
+      if (E.ncon >= NCON_MAX) { E.warn |= WARN_CONTACTFULL; return; }
+      E.ncon++;
+      const real includemargin = R(pair_includemargin[p]);
+      if (rc[c].dist >= includemargin) continue;
+      real f[9];
+      make_frame(rc[c].frame, f);
+      const int b1 = geom_bodyid[pair_g1[p]], b2 = geom_bodyid[pair_g2[p]];
+      const int dim = pair_dim[p];
+      const real pm = rc[c].dist - includemargin;
+      const real imp = impedance(pair_solimp + 5*p, pm);
+      const real K = R(pair_K[p]), B = R(pair_B[p]);
+      real jn[NVX];
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) jn[j] = 0;
+      add_jac_dir(jn, E, b2, rc[c].pos, f, R(1));
+      add_jac_dir(jn, E, b1, rc[c].pos, f, R(-1));
+      if (dim == 1) {
+        const real Rr = (1 - imp)*R(pair_diag[6*p])/imp;
+        if (!push_row(E, W, jn, pm, K, B, imp, Rr)) return;
+        continue;
+      }
+      // pyramidal: every edge gets 2 mu0^2 R(first edge)
+      const real mu0 = R(pair_friction[5*p]);
+      real R0 = (1 - imp)*R(pair_diag[6*p + 1])/imp;
+      if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
+      const real Rpy = 2*mu0*mu0*R0;
+      for (int k = 1; k < dim; k++) {
+        real jt[NVX], row[NVX];
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) jt[j] = 0;
+        if (k < 3) {
+          add_jac_dir(jt, E, b2, rc[c].pos, f + 3*k, R(1));
+          add_jac_dir(jt, E, b1, rc[c].pos, f + 3*k, R(-1));
+        } else {
+          add_jac_rot(jt, E, b2, f + 3*(k - 3), R(1));
+          add_jac_rot(jt, E, b1, f + 3*(k - 3), R(-1));
+        }
+        const real mu = R(pair_friction[5*p + k - 1]);
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) row[j] = jn[j] + mu*jt[j];
+        if (!push_row(E, W, row, pm, K, B, imp, Rpy)) return;
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) row[j] = jn[j] - mu*jt[j];
+        if (!push_row(E, W, row, pm, K, B, imp, Rpy)) return;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Newton solver on the primal problem (mj_fwdConstraint)
+// ---------------------------------------------------------------------------
+struct LsPoint { real alpha, dcost, d0, d1; };
+
+// cost relative to alpha = 0 (no cancellation), first and second derivative
+DEV void ls_eval(LsPoint& P, real alpha, const Env& E, const Work& W, real q1, real q2) {
+  real dcost = alpha*alpha*q2 + alpha*q1;
+  real d0 = 2*alpha*q2 + q1, d1 = 2*q2;
+  for (int r = 0; r < E.nefc; r++) {
+    const real x0 = W.jar(r), v = W.jv(r), D = W.D(r);
+    const real x = x0 + alpha*v;
+    const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
+    dcost += R(0.5)*D*(a*a - a0*a0);
+    if (x < 0) { d0 += D*x*v; d1 += D*v*v; }
+  }
+  P.alpha = alpha; P.dcost = dcost; P.d0 = d0;
+  P.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+}
+
+DEVN void solve_newton(Env& E, const Work& W, real tol) {
+  real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], H[NM > 0 ? NM : 1];
+  const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
+  const int nefc = E.nefc;
+  symv(Ma, E.qM, E.qacc);
+  real improvement = 0;
+  int iter = 0;
+  for (;; iter++) {
+    // active set, forces, gradient and Hessian in one pass over the rows
+    DMC_UNROLL
+    for (int i = 0; i < NM; i++) H[i] = E.qM[i];
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
+    for (int r = 0; r < nefc; r++) {
+      const real jar = W.jar(r);
+      if (jar < 0) {
+        const real D = W.D(r), f = -D*jar;
+        real row[NVX];
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) row[j] = W.J(r, j);
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) {
+          E.qfrc_constraint[j] += row[j]*f;
+          const real s = D*row[j];
+          DMC_UNROLL
+          for (int k = 0; k <= j; k++) H[tri(j, k)] += s*row[k];
+        }
+      }
+    }
+    real gn = 0;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) {
+      grad[i] = Ma[i] - E.qfrc_smooth[i] - E.qfrc_constraint[i];
+      gn += grad[i]*grad[i];
+    }
+    if (iter > 0 && (scale*improvement < tol || scale*sqrt(gn) < tol)) break;
+    if (iter >= ITERATIONS) break;
+    chol_factor(H);
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) search[i] = -grad[i];
+    chol_solve(search, H);
+    real sn = 0;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) sn += search[i]*search[i];
+    sn = sqrt(sn);
+    if (sn < DMC_MINVAL) break;
+    const real gtol = tol*R(0.01)*sn/scale;
+    symv(Mv, E.qM, search);
+    real q1 = 0, q2 = 0;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) {
+      q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
+      q2 += R(0.5)*search[i]*Mv[i];
+    }
+    for (int r = 0; r < nefc; r++) {
+      real s = 0;
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) s += W.J(r, j)*search[j];
+      W.jv(r) = s;
+    }
+    // exact line search: safeguarded Newton on the directional derivative
+    LsPoint p0, p, best;
+    ls_eval(p0, 0, E, W, q1, q2);
+    if (!(p0.d0 < 0)) break;
+    best = p0;
+    real lo = 0, hi = 0, a = -p0.d0/p0.d1;
+    bool have_hi = false;
+    for (int it = 0; it < 50; it++) {
+      ls_eval(p, a, E, W, q1, q2);
+      if (p.dcost < best.dcost) best = p;
+      if (fabs(p.d0) < gtol) break;
+      if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
+      real an = a - p.d0/p.d1;
+      if (have_hi) {
+        if (!(an > lo && an < hi)) an = R(0.5)*(lo + hi);
+        if (hi - lo < R(1e-6)*hi) break;
+      } else if (an <= lo) {
+        an = 2*a;
+      }
+      a = an;
+    }
+    const real alpha = best.alpha;
+    if (alpha == 0) break;
+    improvement = -best.dcost;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) { E.qacc[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
+    for (int r = 0; r < nefc; r++) W.jar(r) += alpha*W.jv(r);
+  }
+  E.iters = iter;
+}
+
+// forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms
+DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
+  kinematics(E);
+  com_pos(E);
+  crb_factor(E);
+  com_vel(E);
+  smooth_forces(E, actuation);
+  E.ncon = 0; E.nefc = 0; E.iters = 0;
+  limit_rows(E, W);
+  if (NPAIR > 0) contact_rows(E, W);
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
+  if (E.nefc == 0) {
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) E.qacc[i] = E.qacc_smooth[i];
+  } else {
+    // warmstart: better of previous qacc and the unconstrained acceleration
+    bool use_warm = false;
+    if (!(DISABLEFLAGS & DSBL_WARMSTART)) {
+      real Ma[NVX], cw = 0, cs = 0;
+      symv(Ma, E.qM, E.warm);
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++)
+        cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
+      for (int r = 0; r < E.nefc; r++) {
+        real jw = 0, js = 0;
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) {
+          const real v = W.J(r, j);
+          jw += v*E.warm[j]; js += v*E.qacc_smooth[j];
+        }
+        const real aref = W.aref(r), D = W.D(r);
+        jw -= aref; js -= aref;
+        if (jw < 0) cw += R(0.5)*D*jw*jw;
+        if (js < 0) cs += R(0.5)*D*js*js;
+        W.jar(r) = jw; W.jv(r) = js;
+      }
+      use_warm = !(cw > cs);
+    }
+    if (use_warm) {
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) E.qacc[i] = E.warm[i];
+    } else {
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) E.qacc[i] = E.qacc_smooth[i];
+      if (DISABLEFLAGS & DSBL_WARMSTART) {
+        for (int r = 0; r < E.nefc; r++) {
+          real js = 0;
+          DMC_UNROLL
+          for (int j = 0; j < NV; j++) js += W.J(r, j)*E.qacc_smooth[j];
+          W.jar(r) = js - W.aref(r);
+        }
+      } else {
+        for (int r = 0; r < E.nefc; r++) W.jar(r) = W.jv(r);
+      }
+    }
+    solve_newton(E, W, tol);
+  }
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) E.warm[i] = E.qacc[i];
+}
+
+DEV void integrate_pos(real* qpos, const real* qvel, real h) {
+  DMC_UNROLL
+  for (int j = 0; j < NJNT; j++) {
+    const int qa = jnt_qposadr[j], da = jnt_dofadr[j];
+    if (jnt_type[j] == JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += h*qvel[da + k];
+      quat_integrate(qpos + qa + 3, qvel + da + 3, h);
+    } else if (jnt_type[j] == JNT_BALL) {
+      quat_integrate(qpos + qa, qvel + da, h);
+    } else {
+      qpos[qa] += h*qvel[da];
+    }
+  }
+}
+
+DEV void reset_state(Env& E, real& time) {   // mj_resetData
+  DMC_UNROLL
+  for (int i = 0; i < NQ; i++) E.qpos[i] = R(qpos0[i]);
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) { E.qvel[i] = 0; E.warm[i] = 0; }
+  DMC_UNROLL
+  for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
+  time = 0;
+}
+DEV bool check_state(Env& E, real& time) {   // mj_checkPos / mj_checkVel
+  bool bp = false, bv = false;
+  DMC_UNROLL
+  for (int i = 0; i < NQ; i++) bp |= bad(E.qpos[i]);
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) bv |= bad(E.qvel[i]);
+  if (bp) { E.warn |= WARN_BADQPOS; reset_state(E, time); }
+  else if (bv) { E.warn |= WARN_BADQVEL; reset_state(E, time); }
+  return bp || bv;
+}
+
+// one `Physics.step()`: finish the step from the current state
+DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
+  const real h = R(timestep);
+  check_state(E, time);
+  if (INTEGRATOR == 0) {
+    forward(E, W, true, tol);
+    bool ba = false;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) ba |= bad(E.qacc[i]);
+    if (ba) { E.warn |= WARN_BADQACC; reset_state(E, time); return; }
+    bool damped = false;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) damped |= dof_damping[i] > 0;
+    real qacc[NVX];
+    if (damped) {
+      real A[NM > 0 ? NM : 1];
+      DMC_UNROLL
+      for (int i = 0; i < NM; i++) A[i] = E.qM[i];
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) {
+        A[tri(i, i)] += h*R(dof_damping[i]);
+        qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
+      }
+      chol_factor(A);
+      chol_solve(qacc, A);
+    } else {
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) qacc[i] = E.qacc[i];
+    }
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) E.qvel[i] += h*qacc[i];
+    integrate_pos(E.qpos, E.qvel, h);
+    time += h;
+  } else {
+    // RK4 (tableau and stage handling as SURVEY.md Appendix A)
+    real q0[NQ > 0 ? NQ : 1], v0[NVX], Fv[4*NVX], Fa[4*NVX], dv[NVX];
+    const real t0 = time;
+    DMC_UNROLL
+    for (int i = 0; i < NQ; i++) q0[i] = E.qpos[i];
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) v0[i] = E.qvel[i];
+    forward(E, W, true, tol);
+    bool ba = false;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) ba |= bad(E.qacc[i]);
+    if (ba) { E.warn |= WARN_BADQACC; reset_state(E, time); return; }
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) { Fv[i] = E.qvel[i]; Fa[i] = E.qacc[i]; }
+    const real Acoef[3] = {R(0.5), R(0.5), R(1)};
+    for (int s = 1; s < 4; s++) {
+      const real a = Acoef[s - 1];
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) {
+        dv[i] = a*Fv[(s - 1)*NV + i];
+        E.qvel[i] = v0[i] + h*a*Fa[(s - 1)*NV + i];
+      }
+      DMC_UNROLL
+      for (int i = 0; i < NQ; i++) E.qpos[i] = q0[i];
+      integrate_pos(E.qpos, dv, h);
+      forward(E, W, true, tol);
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) { Fv[s*NV + i] = E.qvel[i]; Fa[s*NV + i] = E.qacc[i]; }
+    }
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) {
+      dv[i] = (Fv[i] + 2*Fv[NV + i] + 2*Fv[2*NV + i] + Fv[3*NV + i])*R(1.0/6.0);
+      const real acc = (Fa[i] + 2*Fa[NV + i] + 2*Fa[2*NV + i] + Fa[3*NV + i])*R(1.0/6.0);
+      E.qvel[i] = v0[i] + h*acc;
+    }
+    DMC_UNROLL
+    for (int i = 0; i < NQ; i++) E.qpos[i] = q0[i];
+    integrate_pos(E.qpos, dv, h);
+    time = t0 + h;
+  }
+}
+
+// position/velocity quantities the tasks and sensors read (the part of
+// mj_step1 that the observation needs)
+DEV void observe_stage(Env& E, real& time) {
+  check_state(E, time);
+  kinematics(E);
+  com_pos(E);
+  com_vel(E);
+  subtree_vel(E);
+}
+
+// ---------------------------------------------------------------------------
+// task layer: rewards.tolerance + per-domain observation/reward
+// (/root/reference/dm_control/utils/rewards.py:93-135 and suite/*.py)
+// ---------------------------------------------------------------------------
+enum { SIG_GAUSSIAN = 0, SIG_LINEAR = 1, SIG_QUADRATIC = 2 };
+DEV real tolerance(real x, real lower, real upper, real margin, int sigmoid,
+                   real value_at_margin) {
+  const bool in_bounds = lower <= x && x <= upper;
+  if (in_bounds) return 1;
+  if (margin == 0) return 0;
+  const real d = (x < lower ? lower - x : x - upper)/margin;
+  if (sigmoid == SIG_GAUSSIAN) {
+    const real scale = sqrt(-2*log(value_at_margin));
+    return exp(R(-0.5)*(d*scale)*(d*scale));
+  } else if (sigmoid == SIG_LINEAR) {
+    const real sx = d*(1 - value_at_margin);
+    return fabs(sx) < 1 ? 1 - sx : R(0);
+  } else {
+    const real sx = d*sqrt(1 - value_at_margin);
+    return fabs(sx) < 1 ? 1 - sx*sx : R(0);
+  }
+}
+
+#define OBS(k) a.obs[(long long)(k)*a.obs_sk + (long long)e*a.obs_se]
+
+DEV real task_outputs(const Env& E, const DmcArgs& a, int e) {
+  real reward = 0;
+  const real inf = R(1e30);
+  if (TASK == TASK_CARTPOLE) {
+    // cartpole.py:145-148,197-225: position = [x, cos, sin per pole], velocity
+    const int npole = NBODY - 2;
+    OBS(0) = E.qpos[0];
+    real upright = 0, sparse_angle = 1, minvel = 1;
+    for (int p = 0; p < npole; p++) {
+      const real czz = E.xmat[9*(2 + p) + 8], sxz = E.xmat[9*(2 + p) + 2];
+      OBS(1 + 2*p) = czz; OBS(2 + 2*p) = sxz;
+      upright += (czz + 1)*R(0.5);
+      sparse_angle *= tolerance(czz, R(0.995), R(1), 0, SIG_GAUSSIAN, R(0.1));
+    }
+    for (int i = 0; i < NV; i++) OBS(1 + 2*npole + i) = E.qvel[i];
+    if (a.task_param_i & 1) {   // sparse
+      reward = tolerance(E.qpos[0], R(-0.25), R(0.25), 0, SIG_GAUSSIAN, R(0.1))*sparse_angle;
+    } else {
+      upright /= npole;
+      real centered = tolerance(E.qpos[0], 0, 0, 2, SIG_GAUSSIAN, R(0.1));
+      centered = (1 + centered)*R(0.5);
+      real small_control = tolerance(E.ctrl[0], 0, 0, 1, SIG_QUADRATIC, 0);
+      small_control = (4 + small_control)/5;
+      for (int i = 1; i < NV; i++) {
+        const real t = tolerance(E.qvel[i], 0, 0, 5, SIG_GAUSSIAN, R(0.1));
+        minvel = t < minvel ? t : minvel;
+      }
+      const real small_velocity = (1 + minvel)*R(0.5);
+      reward = upright*small_control*small_velocity*centered;
+    }
+  } else if (TASK == TASK_CHEETAH) {
+    // cheetah.py:79-93
+    for (int i = 1; i < NQ; i++) OBS(i - 1) = E.qpos[i];
+    for (int i = 0; i < NV; i++) OBS(NQ - 1 + i) = E.qvel[i];
+    const real speed = E.subtree_linvel[3*task_body[0]];
+    reward = tolerance(speed, 10, inf, 10, SIG_LINEAR, 0);
+  } else if (TASK == TASK_HUMANOID) {
+    // humanoid.py:96-129,168-207; task_body = torso, head, l_hand, l_foot, r_hand, r_foot
+    const int torso = task_body[0], head = task_body[1];
+    int o = 0;
+    for (int i = 7; i < NQ; i++) OBS(o++) = E.qpos[i];
+    const real head_height = E.xpos[3*head + 2];
+    OBS(o++) = head_height;
+    for (int l = 0; l < 4; l++) {
+      const int b = task_body[2 + l];
+      real d[3];
+      for (int k = 0; k < 3; k++) d[k] = E.xpos[3*b + k] - E.xpos[3*torso + k];
+      for (int c = 0; c < 3; c++)
+        OBS(o++) = d[0]*E.xmat[9*torso + c] + d[1]*E.xmat[9*torso + 3 + c] +
+                   d[2]*E.xmat[9*torso + 6 + c];
+    }
+    for (int c = 0; c < 3; c++) OBS(o++) = E.xmat[9*torso + 6 + c];
+    const real* cv = E.subtree_linvel + 3*torso;
+    for (int c = 0; c < 3; c++) OBS(o++) = cv[c];
+    for (int i = 0; i < NV; i++) OBS(o++) = E.qvel[i];
+    const real standing = tolerance(head_height, R(1.4), inf, R(0.35), SIG_GAUSSIAN, R(0.1));
+    const real upright = tolerance(E.xmat[9*torso + 8], R(0.9), inf, R(1.9), SIG_LINEAR, 0);
+    real sc = 0;
+    for (int i = 0; i < NU; i++) sc += tolerance(E.ctrl[i], 0, 0, 1, SIG_QUADRATIC, 0);
+    const real small_control = (4 + sc/NU)/5;
+    const real move_speed = R(a.task_param_r[0]);
+    if (move_speed == 0) {
+      const real dont_move = R(0.5)*(tolerance(cv[0], 0, 0, 2, SIG_GAUSSIAN, R(0.1)) +
+                                     tolerance(cv[1], 0, 0, 2, SIG_GAUSSIAN, R(0.1)));
+      reward = small_control*standing*upright*dont_move;
+    } else {
+      const real speed = sqrt(cv[0]*cv[0] + cv[1]*cv[1]);
+      real move = tolerance(speed, move_speed, inf, move_speed, SIG_LINEAR, 0);
+      move = (5*move + 1)/6;
+      reward = small_control*standing*upright*move;
+    }
+  } else {
+    for (int i = 0; i < NQ; i++) OBS(i) = E.qpos[i];
+    for (int i = 0; i < NV; i++) OBS(NQ + i) = E.qvel[i];
+  }
+  return reward;
+}
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
+  const long long n = a.nenv;
+  DMC_UNROLL
+  for (int i = 0; i < NQ; i++) E.qpos[i] = a.qpos[i*n + e];
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) { E.qvel[i] = a.qvel[i*n + e]; E.warm[i] = a.warm[i*n + e]; }
+  time = a.time[e];
+  E.warn = 0; E.ncon = 0; E.nefc = 0; E.iters = 0;
+}
+DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
+  const long long n = a.nenv;
+  DMC_UNROLL
+  for (int i = 0; i < NQ; i++) a.qpos[i*n + e] = E.qpos[i];
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) { a.qvel[i*n + e] = E.qvel[i]; a.warm[i*n + e] = E.warm[i]; }
+  a.time[e] = time;
+  if (E.warn) a.warn[e] |= E.warn;
+}
+DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate) {
+  const long long n = a.nenv;
+  const real rew = task_outputs(E, a, e);
+  a.reward[e] = rew;
+  if (accumulate) a.episode_return[e] += rew;
+  for (int s = 0; s < NSENSOR; s++) {
+    const int adr = sensor_adr[s], o = sensor_objid[s];
+    if (sensor_type[s] == 35)
+      for (int k = 0; k < 3; k++) a.sensordata[(adr + k)*n + e] = E.subtree_linvel[3*o + k];
+    else if (sensor_type[s] == 34)
+      for (int k = 0; k < 3; k++) a.sensordata[(adr + k)*n + e] = E.subtree_com[3*o + k];
+    else if (sensor_type[s] == 8)
+      a.sensordata[adr*n + e] = E.qpos[jnt_qposadr[o]];
+    else if (sensor_type[s] == 9)
+      a.sensordata[adr*n + e] = E.qvel[jnt_dofadr[o]];
+  }
+  if (a.xpos) for (int i = 0; i < NBODY*3; i++) a.xpos[i*n + e] = E.xpos[i];
+  if (a.xmat) for (int i = 0; i < NBODY*9; i++) a.xmat[i*n + e] = E.xmat[i];
+  a.stats[e] = E.ncon; a.stats[n + e] = E.nefc; a.stats[2*n + e] = E.iters;
+}
+
+// nsub x Physics.step, then observation + reward of the new state.
+// flags bit0: ctrl given (else reuse ctrl_store); bit1: skip outputs (settle)
+extern "C" __global__ void __launch_bounds__(64)
+dmc_step(DmcArgs a) {
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= a.nenv) return;
+  Env E;
+  real time;
+  load_env(E, a, e, time);
+  const long long n = a.nenv;
+  if (a.flags & 1) {
+    bool bc = false;
+    for (int i = 0; i < NU; i++) {
+      E.ctrl[i] = a.ctrl[i*a.ctrl_sk + (long long)e*a.ctrl_se];
+      bc |= bad(E.ctrl[i]);
+    }
+    if (bc) {   // mj_fwdActuation's ctrl check: warn and zero the controls
+      E.warn |= WARN_BADCTRL;
+      for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
+    }
+    for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
+  } else {
+    for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
+  }
+  Work W = {a.ws, n, e};
+  const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
+  for (int s = 0; s < a.nsub; s++) physics_step(E, W, time, tol);
+  if (a.qacc) for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];
+  if (!(a.flags & 2)) {
+    observe_stage(E, time);
+    store_outputs(E, a, e, true);
+  }
+  store_env(E, a, e, time);
+}
+
+// observation / reward / sensors of the current state (reset, after_reset)
+extern "C" __global__ void __launch_bounds__(64)
+dmc_observe(DmcArgs a) {
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= a.nenv) return;
+  Env E;
+  real time;
+  load_env(E, a, e, time);
+  const long long n = a.nenv;
+  for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
+  observe_stage(E, time);
+  if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
+    Work W = {a.ws, n, e};
+    E.ncon = 0; E.nefc = 0;
+    if (NPAIR > 0) contact_rows(E, W);
+  }
+  store_outputs(E, a, e, false);
+  store_env(E, a, e, time);
+}
+
+// stateless counter-based generator for on-device episode initialisation
+DEV uint32_t mix32(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (uint32_t)(x >> 16);
+}
+struct Rng {
+  uint64_t key; uint32_t ctr;
+  __device__ real uniform() {   // [0, 1)
+    return (real)((mix32(key + 0x9e3779b97f4a7c15ULL*(++ctr)) >> 8)*(1.0/16777216.0));
+  }
+  __device__ real normal() {
+    real u1 = uniform(), u2 = uniform();
+    if (u1 < R(1e-7)) u1 = R(1e-7);
+    return sqrt(-2*log(u1))*cos(R(6.283185307179586)*u2);
+  }
+};
+
+// task.initialize_episode on device (distributional equivalent of
+// cartpole.py:177-195, cheetah.py:63-70, randomizers.py:35-86; the host RNG
+// stream of the reference cannot be reproduced in a batched kernel).
+// flags bit3: only redraw envs whose stats[ncon] > 0 (humanoid rejection loop)
+extern "C" __global__ void __launch_bounds__(64)
+dmc_init_episode(DmcArgs a) {
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= a.nenv) return;
+  const long long n = a.nenv;
+  if ((a.flags & 8) && a.stats[e] == 0) return;
+  Rng rng = {a.seed*0x2545F4914F6CDD1DULL + (uint64_t)e, 0};
+  real qpos[NQ > 0 ? NQ : 1], qvel[NVX];
+  for (int i = 0; i < NQ; i++) qpos[i] = R(qpos0[i]);
+  for (int i = 0; i < NV; i++) qvel[i] = 0;
+  if (a.flags & DMC_FLAG_RESET_ONLY) {
+    // mj_resetData only
+  } else if (TASK == TASK_CARTPOLE) {
+    if (a.task_param_i & 2) {   // swing_up
+      qpos[0] = R(0.01)*rng.normal();
+      qpos[1] = R(3.141592653589793) + R(0.01)*rng.normal();
+      for (int i = 2; i < NQ; i++) qpos[i] = R(0.1)*rng.normal();
+    } else {
+      qpos[0] = R(-0.1) + R(0.2)*rng.uniform();
+      for (int i = 1; i < NQ; i++) qpos[i] = R(-0.034) + R(0.068)*rng.uniform();
+    }
+    for (int i = 0; i < NV; i++) qvel[i] = R(0.01)*rng.normal();
+  } else if (TASK == TASK_CHEETAH || TASK == TASK_HUMANOID) {
+    for (int j = 0; j < NJNT; j++) {
+      const int qa = jnt_qposadr[j];
+      if (jnt_limited[j] && (jnt_type[j] == JNT_HINGE || jnt_type[j] == JNT_SLIDE)) {
+        const real lo = R(jnt_range[2*j]), hi = R(jnt_range[2*j + 1]);
+        qpos[qa] = lo + (hi - lo)*rng.uniform();
+      } else if (TASK == TASK_HUMANOID && !jnt_limited[j]) {
+        if (jnt_type[j] == JNT_HINGE) {
+          qpos[qa] = R(-3.141592653589793) + R(6.283185307179586)*rng.uniform();
+        } else if (jnt_type[j] == JNT_FREE) {
+          real q[4];
+          for (int k = 0; k < 4; k++) q[k] = rng.uniform();
+          normalize4(q);
+          for (int k = 0; k < 4; k++) qpos[qa + 3 + k] = q[k];
+        }
+      }
+    }
+  }
+  for (int i = 0; i < NQ; i++) a.qpos[i*n + e] = qpos[i];
+  for (int i = 0; i < NV; i++) { a.qvel[i*n + e] = qvel[i]; a.warm[i*n + e] = 0; }
+  for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = 0;
+  a.time[e] = 0;
+  a.episode_return[e] = 0;
+}
+
+// self-description read by dmc_api.cpp through hipModuleGetGlobal
+extern "C" __device__ const int dmc_info[16] = {
+    1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
+    NEFC_MAX*(NV + 4) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
+    INTEGRATOR, NPAIR, 0, 0};

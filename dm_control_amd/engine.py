@@ -1,0 +1,450 @@
+"""Batched `Physics` on the MI355X step kernels.
+
+Mirror of the reference's `mujoco.Physics`
+(/root/reference/dm_control/mujoco/engine.py:86-573) for B independent
+instances that live in HBM.  Same method names and meaning:
+
+  step           engine.py:149-166   (mj_step2|mj_step, then mj_step1) x n
+  set_control    engine.py:141-147
+  reset          engine.py:268-289   after_reset :291-295   forward :297-305
+  check_invalid_state  :307-330      (mjtWarning bits -> PhysicsError)
+  get_state/set_state  :217-245      copy :247-266
+  action_spec    engine.py:1018-1028
+
+With `batch_size=None` the object behaves like the reference's single
+instance (arrays without a batch axis, python-float time); with an integer
+every array gets a leading batch axis.  Field access (`physics.data.qpos`,
+`physics.named.data.xpos['head', 'z']`) returns host copies; assignment writes
+through to device memory.
+"""
+
+import collections
+import contextlib
+import logging
+
+import numpy as np
+
+from dm_control_amd import _dm_env as dm_env
+from dm_control_amd import build
+from dm_control_amd import codegen
+from dm_control_amd import wrapper
+from dm_control_amd.mjcf import compiler
+from dm_control_amd.mjcf import model as mdl
+from dm_control_amd.rl import control as _control
+
+specs = dm_env.specs
+
+_INVALID_PHYSICS_STATE = (
+    'Physics state is invalid. Warning(s) raised: {warning_names}')
+
+Contexts = collections.namedtuple('Contexts', ['gl', 'mujoco'])
+
+
+class _Field:
+  """Host view of one device field with write-through assignment.
+
+  Reads copy device -> host; `field[idx] = v` is read-modify-write.  The batch
+  axis leads (agent layout) and is dropped for an unbatched Physics.
+  """
+
+  def __init__(self, physics, field, width=None, writable=None):
+    self._p = physics
+    self._f = field
+    self._width = width
+    self._writable = writable
+
+  def _get(self):
+    p = self._p
+    a = p._batch.read(self._f)
+    if self._f == wrapper.FIELD_OBS:
+      out = a
+    elif a.ndim == 2:
+      out = a.T
+      if self._width is not None:
+        out = out[:, :self._width]
+    else:
+      out = a
+    out = np.ascontiguousarray(out)
+    if self._f not in (wrapper.FIELD_WARN, wrapper.FIELD_STATS):
+      out = out.astype(np.float64)
+    return out[0] if p._squeeze else out
+
+  def _put(self, value):
+    if self._writable is None:
+      raise ValueError('this field is read-only')
+    p = self._p
+    v = np.asarray(value, dtype=np.float64)
+    if p._squeeze:
+      v = v[None]
+    if v.ndim == 2:
+      v = v.T
+    p._batch.set_state(**{self._writable: v})
+    p._dirty = True
+
+  def __array__(self, dtype=None, copy=None):
+    a = self._get()
+    return a.astype(dtype) if dtype is not None else a
+
+  def copy(self):
+    return self._get()
+
+  def __getitem__(self, idx):
+    return self._get()[idx]
+
+  def __setitem__(self, idx, value):
+    a = self._get()
+    a[idx] = value
+    self._put(a)
+
+  def __len__(self):
+    return len(self._get())
+
+  @property
+  def shape(self):
+    return self._get().shape
+
+  def __repr__(self):
+    return repr(self._get())
+
+
+class _NamedField:
+  """`physics.named.data.<field>[row_name(, col_name)]` (mujoco/index.py)."""
+
+  def __init__(self, field, rows, cols=None):
+    self._field = field
+    self._rows = rows      # name -> slice / int along the last-but-cols axis
+    self._cols = cols      # optional name -> int
+
+  def _index(self, key):
+    if isinstance(key, tuple):
+      r, c = key
+    else:
+      r, c = key, None
+    def one(name, table):
+      if isinstance(name, str):
+        if name not in table:
+          raise IndexError('invalid name {!r}'.format(name))
+        return table[name]
+      if isinstance(name, (list, tuple)) and name and isinstance(name[0], str):
+        return [table[n] for n in name]
+      return name
+    return one(r, self._rows), (None if c is None else one(c, self._cols or {}))
+
+  def __getitem__(self, key):
+    r, c = self._index(key)
+    a = self._field._get()
+    if self._cols is not None:
+      a = a.reshape(a.shape[:-1] + (-1, len(self._cols)))
+      out = a[..., r, :]
+      return out if c is None else out[..., c]
+    return a[..., r]
+
+  def __setitem__(self, key, value):
+    r, c = self._index(key)
+    a = self._field._get()
+    if self._cols is not None:
+      b = a.reshape(a.shape[:-1] + (-1, len(self._cols)))
+      if c is None:
+        b[..., r, :] = value
+      else:
+        b[..., r, c] = value
+    else:
+      a[..., r] = value
+    self._field._put(a)
+
+
+class _Data:
+  """`physics.data`: host accessors named like `mjData` fields."""
+
+  def __init__(self, physics):
+    p, m = physics, physics.model
+    W = wrapper
+    self.qpos = _Field(p, W.FIELD_QPOS, m.nq, 'qpos')
+    self.qvel = _Field(p, W.FIELD_QVEL, m.nv, 'qvel')
+    self.qacc_warmstart = _Field(p, W.FIELD_WARMSTART, m.nv, 'warmstart')
+    self.qacc = _Field(p, W.FIELD_QACC, m.nv)
+    self.ctrl = _Field(p, W.FIELD_CTRL, m.nu)
+    self.sensordata = _Field(p, W.FIELD_SENSORDATA, m.nsensordata)
+    self.xpos = _Field(p, W.FIELD_XPOS)
+    self.xmat = _Field(p, W.FIELD_XMAT)
+    self._time = _Field(p, W.FIELD_TIME, None, 'time')
+    self._p = p
+
+  @property
+  def time(self):
+    t = self._time._get()
+    return float(t) if self._p._squeeze else t
+
+  @time.setter
+  def time(self, value):
+    n = self._p._batch.nenv
+    self._p._batch.set_state(time=np.full(n, value, np.float64))
+
+  @property
+  def ncon(self):
+    """Contacts of the most recent collision pass (after `forward`)."""
+    s = self._p._batch.read(wrapper.FIELD_STATS)[0]
+    return int(s[0]) if self._p._squeeze else s
+
+  @property
+  def warning_mask(self):
+    w = self._p._batch.read(wrapper.FIELD_WARN)
+    return int(w[0]) if self._p._squeeze else w
+
+
+class _NamedData:
+
+  def __init__(self, physics, data):
+    m = physics.model
+    jq, jv = {}, {}
+    for j, name in enumerate(m.names['joint']):
+      if not name:
+        continue
+      nq = {mdl.JNT_FREE: 7, mdl.JNT_BALL: 4}.get(int(m.jnt_type[j]), 1)
+      nv = {mdl.JNT_FREE: 6, mdl.JNT_BALL: 3}.get(int(m.jnt_type[j]), 1)
+      a, d = int(m.jnt_qposadr[j]), int(m.jnt_dofadr[j])
+      jq[name] = slice(a, a + nq)
+      jv[name] = slice(d, d + nv)
+    bodies = {n: i for i, n in enumerate(m.names['body']) if n}
+    acts = {n: i for i, n in enumerate(m.names.get('actuator', [])) if n}
+    sens = {}
+    for i, n in enumerate(m.names.get('sensor', [])):
+      if n:
+        a = int(m.sensor_adr[i])
+        sens[n] = slice(a, a + int(m.sensor_dim[i]))
+    xyz = {'x': 0, 'y': 1, 'z': 2}
+    mat = {a + b: 3*i + j for i, a in enumerate('xyz') for j, b in
+           enumerate('xyz')}
+    self.qpos = _NamedField(data.qpos, jq)
+    self.qvel = _NamedField(data.qvel, jv)
+    self.ctrl = _NamedField(data.ctrl, acts)
+    self.sensordata = _NamedField(data.sensordata, sens)
+    self.xpos = _NamedField(data.xpos, bodies, xyz)
+    self.xmat = _NamedField(data.xmat, bodies, mat)
+
+
+class _Named:
+
+  def __init__(self, physics, data):
+    self.data = _NamedData(physics, data)
+    self.model = physics.model
+
+
+class Physics(_control.Physics):
+  """Batched simulation of one compiled MJCF on one MI355X."""
+
+  _TASK = codegen.TASK_NONE   # domain subclasses select the fused task
+
+  def __init__(self, model, batch_size=None, device=0, precision='f32',
+               task=None, ncon_max=None):
+    self.model = model
+    self._squeeze = batch_size is None
+    self._batch_size = 1 if batch_size is None else int(batch_size)
+    self._task_id = self._TASK if task is None else task
+    self._precision = precision
+    self._device = device
+    self._ncon_max = ncon_max
+    self._warnings_cause_exception = True
+    self._pending_ctrl = None
+    self._dirty = True
+    path = build.build_model(model, self._task_id, precision, ncon_max)
+    self._hip_model = wrapper.HipModel(path, device)
+    self._batch = wrapper.HipBatch(self._hip_model, self._batch_size)
+    self.data = _Data(self)
+    self.named = _Named(self, self.data)
+    self._warn_seen = np.zeros(self._batch_size, np.uint32)
+
+  # -- constructors (engine.py:411-470) ------------------------------------------
+  @classmethod
+  def from_xml_string(cls, xml_string, assets=None, **kwargs):
+    return cls(compiler.from_xml_string(xml_string, assets), **kwargs)
+
+  @classmethod
+  def from_xml_path(cls, file_path, **kwargs):
+    return cls(compiler.from_xml_path(file_path), **kwargs)
+
+  @classmethod
+  def from_model(cls, model, **kwargs):
+    return cls(model, **kwargs)
+
+  # -- properties -----------------------------------------------------------------
+  @property
+  def batch_size(self):
+    return None if self._squeeze else self._batch_size
+
+  @property
+  def batch(self):
+    """The underlying `wrapper.HipBatch` (device pointers, raw fields)."""
+    return self._batch
+
+  @property
+  def dtype(self):
+    return self._hip_model.dtype
+
+  # -- stepping -----------------------------------------------------------------
+  @contextlib.contextmanager
+  def suppress_physics_errors(self):
+    prev = self._warnings_cause_exception
+    self._warnings_cause_exception = False
+    try:
+      yield
+    finally:
+      self._warnings_cause_exception = prev
+
+  def set_control(self, control):
+    """Stores the control applied by subsequent steps (engine.py:141-147)."""
+    c = np.asarray(control, dtype=np.float64)
+    if c.ndim == 1:
+      c = np.broadcast_to(c, (self._batch_size, self.model.nu))
+    if c.shape != (self._batch_size, self.model.nu):
+      raise ValueError('control must have shape ({}, {}), got {}'.format(
+          self._batch_size, self.model.nu, c.shape))
+    self._pending_ctrl = np.ascontiguousarray(c)
+
+  def set_control_device(self, ptr, stride_k, stride_env):
+    """Zero-copy control: a device address plus element strides (in reals)."""
+    self._pending_ctrl = ('device', int(ptr), int(stride_k), int(stride_env))
+
+  def step(self, n_sub_steps=1, outputs=True, check=True):
+    """`n_sub_steps` x (mj_step2|mj_step + mj_step1), one kernel launch."""
+    ctrl = self._pending_ctrl
+    if isinstance(ctrl, tuple):
+      self._batch.step_device(ctrl[1], ctrl[2], ctrl[3], n_sub_steps, outputs)
+    else:
+      self._batch.step_host(ctrl, n_sub_steps, outputs)
+    self._pending_ctrl = None   # ctrl now lives in data.ctrl on the device
+    self._dirty = not outputs
+    if check:
+      self.check_invalid_state()
+
+  def forward(self, count_contacts=False):
+    """Recomputes derived quantities (observation inputs) without stepping."""
+    self._batch.forward(count_contacts)
+    self._dirty = False
+
+  def reset(self):
+    """mj_resetData + forward with actuation disabled (engine.py:268-289)."""
+    self._batch.reset()
+    self._warn_seen[:] = 0
+    self._pending_ctrl = None
+    self.forward()
+
+  def after_reset(self):
+    """engine.py:291-295."""
+    self.forward(count_contacts=True)
+
+  def check_invalid_state(self):
+    """Raises PhysicsError for new mjtWarning bits (engine.py:307-330)."""
+    w = self._batch.read(wrapper.FIELD_WARN)
+    new = w & ~self._warn_seen
+    self._warn_seen = w.copy()
+    if new.any():
+      bits = int(np.bitwise_or.reduce(new))
+      names = [n for i, n in enumerate(mdl.WARNING_NAMES) if bits & (1 << i)]
+      message = _INVALID_PHYSICS_STATE.format(warning_names=', '.join(names))
+      if self._warnings_cause_exception:
+        raise _control.PhysicsError(
+            message + ' (envs {})'.format(np.nonzero(new)[0][:8].tolist()))
+      logging.warning(message)
+
+  check_divergence = check_invalid_state
+
+  # -- fused task outputs ---------------------------------------------------------
+  def _ensure_outputs(self):
+    if self._dirty:
+      self.forward()
+
+  def fused_observation(self):
+    """[B, nobs] (or [nobs]) observation vector written by the last launch."""
+    self._ensure_outputs()
+    return self._squeeze_out(
+        self._batch.read(wrapper.FIELD_OBS).astype(np.float64))
+
+  def fused_reward(self):
+    self._ensure_outputs()
+    r = self._batch.read(wrapper.FIELD_REWARD).astype(np.float64)
+    return float(r[0]) if self._squeeze else r
+
+  def _squeeze_out(self, a):
+    return a[0] if self._squeeze else a
+
+  # -- state accessors (engine.py:217-245, 520-573) ----------------------------
+  def time(self):
+    return self.data.time
+
+  def timestep(self):
+    return self.model.opt.timestep
+
+  def control(self):
+    if isinstance(self._pending_ctrl, np.ndarray):
+      return self._squeeze_out(self._pending_ctrl.copy())
+    return self.data.ctrl.copy()
+
+  def position(self):
+    return self.data.qpos.copy()
+
+  def velocity(self):
+    return self.data.qvel.copy()
+
+  def activation(self):
+    shape = (0,) if self._squeeze else (self._batch_size, 0)
+    return np.zeros(shape)
+
+  def state(self):
+    return np.concatenate(self._physics_state_items(), axis=-1)
+
+  def _physics_state_items(self):
+    return [self.position(), self.velocity(), self.activation()]
+
+  def get_state(self):
+    return np.concatenate(self._physics_state_items(), axis=-1)
+
+  def set_state(self, physics_state):
+    physics_state = np.asarray(physics_state, np.float64)
+    nq, nv = self.model.nq, self.model.nv
+    expected = ((nq + nv,) if self._squeeze
+                else (self._batch_size, nq + nv))
+    if physics_state.shape != expected:
+      raise ValueError('Input physics state has shape {}. Expected {}.'
+                       .format(physics_state.shape, expected))
+    s = physics_state.reshape(self._batch_size, nq + nv)
+    self._batch.set_state(qpos=s[:, :nq].T, qvel=s[:, nq:].T)
+    self._dirty = True
+
+  def copy(self, share_model=True):
+    del share_model  # the compiled model is immutable and always shared
+    new = type(self).__new__(type(self))
+    Physics.__init__(new, self.model,
+                     None if self._squeeze else self._batch_size,
+                     self._device, self._precision, self._task_id,
+                     self._ncon_max)
+    new._batch.copy_state_from(self._batch)
+    new._warn_seen = self._warn_seen.copy()
+    new._dirty = self._dirty
+    return new
+
+  def set_task_params(self, iparam=0, rparams=()):
+    self._batch.set_task_params(iparam, rparams)
+
+  def free(self):
+    self._batch.free()
+    self._hip_model.free()
+
+  # context-manager parity with engine.py:392-409
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *unused):
+    self.free()
+
+
+def action_spec(physics):
+  """`BoundedArray` matching the actuators (engine.py:1018-1028)."""
+  m = physics.model
+  num_actions = m.nu
+  is_limited = m.actuator_ctrllimited.ravel().astype(bool)
+  minima = np.full(num_actions, fill_value=-mdl.MJ_MAXVAL, dtype=np.float64)
+  maxima = np.full(num_actions, fill_value=mdl.MJ_MAXVAL, dtype=np.float64)
+  minima[is_limited], maxima[is_limited] = m.actuator_ctrlrange[is_limited].T
+  return specs.BoundedArray(shape=(num_actions,), dtype=np.float64,
+                            minimum=minima, maximum=maxima)

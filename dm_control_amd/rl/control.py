@@ -1,0 +1,258 @@
+"""Batched `control.Environment` for the MI355X physics step.
+
+Same orchestration, step counting, time-limit and `TimeStep` conventions as the
+reference (/root/reference/dm_control/rl/control.py:28-161), applied to B
+instances that advance in lock step:
+
+  * `reset()`  -> FIRST, reward None, discount None              (:77-92)
+  * `step(a)`  -> MID with discount 1.0, or LAST at the time limit with
+                  discount 1.0, or LAST with `task.get_termination`  (:94-123)
+  * the call after LAST resets and ignores the action             (:97-98)
+  * `n_sub_steps` from `control_timestep` via `compute_n_steps`   (:164-190)
+
+The `n_sub_steps` physics steps, the task observation and the reward of one
+control step are a single kernel launch (`physics.step(n_sub_steps)`).
+With an unbatched Physics the TimeStep holds python floats and un-batched
+arrays exactly like the reference; with a batch every leaf gains a leading B.
+"""
+
+import abc
+import collections
+import contextlib
+
+import numpy as np
+
+from dm_control_amd import _dm_env as dm_env
+
+specs = dm_env.specs
+
+FLAT_OBSERVATION_KEY = 'observations'
+
+
+class Environment(dm_env.Environment):
+  """Physics-based RL environment over a batch of instances."""
+
+  def __init__(self, physics, task, time_limit=float('inf'),
+               control_timestep=None, n_sub_steps=None,
+               flat_observation=False):
+    self._task = task
+    self._physics = physics
+    self._flat_observation = flat_observation
+    if n_sub_steps is not None and control_timestep is not None:
+      raise ValueError('Both n_sub_steps and control_timestep were supplied.')
+    elif n_sub_steps is not None:
+      self._n_sub_steps = n_sub_steps
+    elif control_timestep is not None:
+      self._n_sub_steps = compute_n_steps(control_timestep,
+                                          self._physics.timestep())
+    else:
+      self._n_sub_steps = 1
+    if time_limit == float('inf'):
+      self._step_limit = float('inf')
+    else:
+      self._step_limit = time_limit / (
+          self._physics.timestep() * self._n_sub_steps)
+    self._step_count = 0
+    self._reset_next_step = True
+
+  def reset(self):
+    """Starts a new episode (all instances) and returns the first TimeStep."""
+    self._reset_next_step = False
+    self._step_count = 0
+    with self._physics.reset_context():
+      self._task.initialize_episode(self._physics)
+    observation = self._task.get_observation(self._physics)
+    if self._flat_observation:
+      observation = flatten_observation(observation)
+    return dm_env.TimeStep(step_type=dm_env.StepType.FIRST, reward=None,
+                           discount=None, observation=observation)
+
+  def step(self, action):
+    """Advances every instance by one control step."""
+    if self._reset_next_step:
+      return self.reset()
+    self._task.before_step(action, self._physics)
+    self._physics.step(self._n_sub_steps)
+    self._task.after_step(self._physics)
+    reward = self._task.get_reward(self._physics)
+    observation = self._task.get_observation(self._physics)
+    if self._flat_observation:
+      observation = flatten_observation(observation)
+    self._step_count += 1
+    if self._step_count >= self._step_limit:
+      discount = 1.0
+    else:
+      discount = self._task.get_termination(self._physics)
+    episode_over = discount is not None
+    batch = getattr(self._physics, 'batch_size', None)
+    if episode_over:
+      self._reset_next_step = True
+      if batch is not None and np.isscalar(discount):
+        discount = np.full(batch, discount, np.float64)
+      return dm_env.TimeStep(dm_env.StepType.LAST, reward, discount,
+                             observation)
+    discount = 1.0 if batch is None else np.ones(batch, np.float64)
+    return dm_env.TimeStep(dm_env.StepType.MID, reward, discount, observation)
+
+  def action_spec(self):
+    return self._task.action_spec(self._physics)
+
+  def step_spec(self):
+    return self._task.step_spec(self._physics)
+
+  def observation_spec(self):
+    try:
+      return self._task.observation_spec(self._physics)
+    except NotImplementedError:
+      observation = self._task.get_observation(self._physics)
+      if self._flat_observation:
+        observation = flatten_observation(observation)
+      return _spec_from_observation(observation)
+
+  @property
+  def physics(self):
+    return self._physics
+
+  @property
+  def task(self):
+    return self._task
+
+  @property
+  def batch_size(self):
+    return getattr(self._physics, 'batch_size', None)
+
+  def control_timestep(self):
+    return self.physics.timestep() * self._n_sub_steps
+
+
+def compute_n_steps(control_timestep, physics_timestep, tolerance=1e-8):
+  """Number of physics steps per control step (control.py:164-190)."""
+  if control_timestep < physics_timestep:
+    raise ValueError(
+        'Control timestep ({}) cannot be smaller than physics timestep ({}).'.
+        format(control_timestep, physics_timestep))
+  if abs((control_timestep / physics_timestep - round(
+      control_timestep / physics_timestep))) > tolerance:
+    raise ValueError(
+        'Control timestep ({}) must be an integer multiple of physics timestep '
+        '({})'.format(control_timestep, physics_timestep))
+  return int(round(control_timestep / physics_timestep))
+
+
+def _spec_from_observation(observation):
+  result = collections.OrderedDict()
+  for key, value in observation.items():
+    value = np.asarray(value)
+    result[key] = specs.Array(value.shape, value.dtype, name=key)
+  return result
+
+
+class Physics(metaclass=abc.ABCMeta):
+  """Simulates a physical environment (control.py:202-261)."""
+
+  @abc.abstractmethod
+  def step(self, n_sub_steps=1):
+    """Updates the simulation state `n_sub_steps` times."""
+
+  @abc.abstractmethod
+  def time(self):
+    """Elapsed simulation time in seconds."""
+
+  @abc.abstractmethod
+  def timestep(self):
+    """Simulation timestep."""
+
+  def set_control(self, control):
+    raise NotImplementedError('set_control is not supported.')
+
+  @contextlib.contextmanager
+  def reset_context(self):
+    """Resets on entry, runs `after_reset` on exit (control.py:226-247)."""
+    try:
+      self.reset()
+    except PhysicsError:
+      pass
+    yield self
+    self.after_reset()
+
+  @abc.abstractmethod
+  def reset(self):
+    """Resets internal variables of the physics simulation."""
+
+  @abc.abstractmethod
+  def after_reset(self):
+    """Runs after resetting internal variables of the physics simulation."""
+
+  def check_divergence(self):
+    """Raises a `PhysicsError` if the simulation state is divergent."""
+
+
+class PhysicsError(RuntimeError):
+  """Raised if the state of the physics simulation becomes divergent."""
+
+
+class Task(metaclass=abc.ABCMeta):
+  """Defines a task in a `control.Environment` (control.py:268-365)."""
+
+  @abc.abstractmethod
+  def initialize_episode(self, physics):
+    """Sets the state of the environment at the start of each episode."""
+
+  @abc.abstractmethod
+  def before_step(self, action, physics):
+    """Updates the task from the provided action."""
+
+  def after_step(self, physics):
+    """Optional hook after the physics step."""
+
+  @abc.abstractmethod
+  def action_spec(self, physics):
+    """Specification of valid actions."""
+
+  def step_spec(self, physics):
+    raise NotImplementedError()
+
+  @abc.abstractmethod
+  def get_observation(self, physics):
+    """Returns an observation from the environment."""
+
+  @abc.abstractmethod
+  def get_reward(self, physics):
+    """Returns a reward from the environment."""
+
+  def get_termination(self, physics):
+    """If the episode should end, returns a final discount, otherwise None."""
+
+  def observation_spec(self, physics):
+    raise NotImplementedError()
+
+
+def flatten_observation(observation, output_key=FLAT_OBSERVATION_KEY):
+  """Concatenates observation leaves in key order (control.py:368-393).
+
+  Leaves keep a leading batch axis if they have one: an unbatched leaf is
+  ravelled to 1-D, a batched [B, ...] leaf to [B, -1].
+  """
+  if not isinstance(observation, collections.abc.MutableMapping):
+    raise ValueError('Can only flatten dict-like observations.')
+  if isinstance(observation, collections.OrderedDict):
+    keys = observation.keys()
+  else:
+    keys = sorted(observation.keys())
+  leaves = [np.asarray(observation[key]) for key in keys]
+  batch = getattr(observation, 'batch_size', None)
+  if batch is None:
+    arrays = [leaf.ravel() for leaf in leaves]
+    flat = np.concatenate(arrays)
+  else:
+    flat = np.concatenate([leaf.reshape(batch, -1) for leaf in leaves], axis=1)
+  out = type(observation)([(output_key, flat)])
+  if batch is not None:
+    out.batch_size = batch
+  return out
+
+
+class BatchedObservation(collections.OrderedDict):
+  """OrderedDict of [B, ...] leaves that remembers its batch size."""
+
+  batch_size = None

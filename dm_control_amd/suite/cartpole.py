@@ -1,0 +1,141 @@
+"""Cartpole domain (cf. /root/reference/dm_control/suite/cartpole.py)."""
+
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from dm_control_amd import codegen
+from dm_control_amd import engine
+from dm_control_amd.rl import control
+from dm_control_amd.suite import base
+from dm_control_amd.suite import common
+from dm_control_amd.utils import containers
+
+_DEFAULT_TIME_LIMIT = 10
+SUITE = containers.TaggedTasks()
+
+
+def get_model_and_assets(num_poles=1):
+  return _make_model(num_poles), common.ASSETS
+
+
+def _make_env(num_poles, swing_up, sparse, time_limit, random,
+              environment_kwargs):
+  phys_kw, task_kw, env_kw = common.split_kwargs(environment_kwargs)
+  physics = Physics.from_xml_string(*get_model_and_assets(num_poles),
+                                    **phys_kw)
+  task = Balance(swing_up=swing_up, sparse=sparse, random=random, **task_kw)
+  physics.set_task_params((1 if sparse else 0) | (2 if swing_up else 0))
+  return control.Environment(physics, task, time_limit=time_limit, **env_kw)
+
+
+@SUITE.add('benchmarking')
+def balance(time_limit=_DEFAULT_TIME_LIMIT, random=None,
+            environment_kwargs=None):
+  """Returns the Cartpole Balance task (cartpole.py:39-47)."""
+  return _make_env(1, False, False, time_limit, random, environment_kwargs)
+
+
+@SUITE.add('benchmarking')
+def balance_sparse(time_limit=_DEFAULT_TIME_LIMIT, random=None,
+                   environment_kwargs=None):
+  return _make_env(1, False, True, time_limit, random, environment_kwargs)
+
+
+@SUITE.add('benchmarking')
+def swingup(time_limit=_DEFAULT_TIME_LIMIT, random=None,
+            environment_kwargs=None):
+  return _make_env(1, True, False, time_limit, random, environment_kwargs)
+
+
+@SUITE.add('benchmarking')
+def swingup_sparse(time_limit=_DEFAULT_TIME_LIMIT, random=None,
+                   environment_kwargs=None):
+  return _make_env(1, True, True, time_limit, random, environment_kwargs)
+
+
+@SUITE.add()
+def two_poles(time_limit=_DEFAULT_TIME_LIMIT, random=None,
+              environment_kwargs=None):
+  return _make_env(2, True, False, time_limit, random, environment_kwargs)
+
+
+@SUITE.add()
+def three_poles(time_limit=_DEFAULT_TIME_LIMIT, random=None, num_poles=3,
+                sparse=False, environment_kwargs=None):
+  return _make_env(num_poles, True, sparse, time_limit, random,
+                   environment_kwargs)
+
+
+def _make_model(n_poles):
+  """Cart with a chain of `n_poles` poles (cartpole.py:105-128)."""
+  xml_string = common.read_model('cartpole.xml')
+  if n_poles == 1:
+    return xml_string
+  mjcf = ET.fromstring(xml_string)
+  parent = mjcf.find('./worldbody/body/body')
+  for pole_index in range(2, n_poles + 1):
+    child = ET.SubElement(parent, 'body', name='pole_{}'.format(pole_index),
+                          pos='0 0 1', childclass='pole')
+    ET.SubElement(child, 'joint', name='hinge_{}'.format(pole_index))
+    ET.SubElement(child, 'geom', name='pole_{}'.format(pole_index))
+    parent = child
+  return ET.tostring(mjcf, encoding='unicode')
+
+
+class Physics(engine.Physics):
+  """Physics with the Cartpole helpers (cartpole.py:131-148)."""
+
+  _TASK = codegen.TASK_CARTPOLE
+
+  def cart_position(self):
+    return self.named.data.qpos['slider'][..., 0]
+
+  def angular_vel(self):
+    return self.data.qvel[..., 1:]
+
+  def pole_angle_cosine(self):
+    return self.named.data.xmat[slice(2, None), 'zz']
+
+  def bounded_position(self):
+    npole = self.model.nbody - 2
+    return self.fused_observation()[..., :1 + 2*npole]
+
+
+class Balance(base.Task):
+  """Balance / swing-up task (cartpole.py:151-225)."""
+
+  _CART_RANGE = (-.25, .25)
+  _ANGLE_COSINE_RANGE = (.995, 1)
+
+  def __init__(self, swing_up, sparse, random=None, device_init=False):
+    self._sparse = sparse
+    self._swing_up = swing_up
+    super().__init__(random=random, device_init=device_init)
+
+  def initialize_episode(self, physics):
+    if self._device_init:
+      physics.batch.init_episode(self.device_seed())
+    else:
+      nv = physics.model.nv
+      rows = []
+      for rs in self.streams(physics):
+        qpos = np.zeros(nv)
+        # same RandomState call order as cartpole.py:186-194
+        if self._swing_up:
+          qpos[0] = .01*rs.randn()
+          qpos[1] = np.pi + .01*rs.randn()
+          qpos[2:] = .1*rs.randn(nv - 2)
+        else:
+          qpos[0] = rs.uniform(-.1, .1)
+          qpos[1:] = rs.uniform(-.034, .034, nv - 1)
+        qvel = 0.01*rs.randn(nv)
+        rows.append(np.concatenate([qpos, qvel]))
+      state = np.array(rows)
+      physics.set_state(state[0] if physics.batch_size is None else state)
+    super().initialize_episode(physics)
+
+  def get_observation(self, physics):
+    npole = physics.model.nbody - 2
+    return self._obs_dict(physics, [('position', 1 + 2*npole, False),
+                                    ('velocity', physics.model.nv, False)])

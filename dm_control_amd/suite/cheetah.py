@@ -1,0 +1,68 @@
+"""Cheetah domain (cf. /root/reference/dm_control/suite/cheetah.py)."""
+
+import numpy as np
+
+from dm_control_amd import codegen
+from dm_control_amd import engine
+from dm_control_amd.rl import control
+from dm_control_amd.suite import base
+from dm_control_amd.suite import common
+from dm_control_amd.utils import containers
+
+_DEFAULT_TIME_LIMIT = 10
+_RUN_SPEED = 10   # fused on the device: tolerance(speed, (10, inf), margin 10)
+_SETTLE_STEPS = 200
+
+SUITE = containers.TaggedTasks()
+
+
+def get_model_and_assets():
+  return common.read_model('cheetah.xml'), common.ASSETS
+
+
+@SUITE.add('benchmarking')
+def run(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None):
+  """Returns the run task (cheetah.py:42-49)."""
+  phys_kw, task_kw, env_kw = common.split_kwargs(environment_kwargs)
+  physics = Physics.from_xml_string(*get_model_and_assets(), **phys_kw)
+  task = Cheetah(random=random, **task_kw)
+  return control.Environment(physics, task, time_limit=time_limit, **env_kw)
+
+
+class Physics(engine.Physics):
+
+  _TASK = codegen.TASK_CHEETAH
+
+  def speed(self):
+    """Horizontal speed of the Cheetah (cheetah.py:55-57)."""
+    return self.named.data.sensordata['torso_subtreelinvel'][..., 0]
+
+
+class Cheetah(base.Task):
+  """Running task (cheetah.py:60-93)."""
+
+  def initialize_episode(self, physics):
+    m = physics.model
+    assert m.nq == m.njnt
+    if self._device_init:
+      physics.batch.init_episode(self.device_seed())
+    else:
+      is_limited = m.jnt_limited == 1
+      lower, upper = m.jnt_range[is_limited].T
+      rows = []
+      for rs in self.streams(physics):
+        qpos = m.qpos0.copy()
+        qpos[is_limited] = rs.uniform(lower, upper)
+        rows.append(qpos)
+      qpos = np.array(rows)
+      physics.data.qpos[:] = qpos[0] if physics.batch_size is None else qpos
+    # Stabilize the model before the actual simulation: 200 physics steps in
+    # one launch, no observation/reward work (cheetah.py:72-73).
+    physics.step(_SETTLE_STEPS, outputs=False)
+    physics.data.time = 0
+    super().initialize_episode(physics)
+
+  def get_observation(self, physics):
+    m = physics.model
+    return self._obs_dict(physics, [('position', m.nq - 1, False),
+                                    ('velocity', m.nv, False)])

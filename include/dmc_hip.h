@@ -1,0 +1,142 @@
+/* dmc_hip.h -- C ABI of the MI355X batched physics step (libdmc_hip.so).
+ *
+ * Drop-in boundary for the path the reference reaches through the ctypes
+ * handle `mjlib` (/root/reference/dm_control/mujoco/wrapper/util.py:107-120).
+ * Every entry point is extern "C", takes plain pointers and sizes, returns an
+ * int status (0 = ok) and leaves a message for dmc_last_error() on failure.
+ * Per-environment physics faults never abort: they are reported through the
+ * sticky `DMC_FIELD_WARN` bit mask whose bit order is mjtWarning
+ * (engine.py:307-330 turns new warnings into PhysicsError).
+ *
+ * Batched counterparts (B = nenv independent instances, struct-of-arrays
+ * [k][env] in device memory unless a stride is given):
+ *
+ *   reference call (file:line)                          this ABI
+ *   --------------------------------------------------  ----------------------
+ *   mj_version            wrapper/core.py:65            dmc_version
+ *   mj_loadXML            wrapper/core.py:312-328       dmc_model_load (*)
+ *   mj_deleteModel        wrapper/core.py:326           dmc_model_free
+ *   mj_makeData           wrapper/core.py:646           dmc_batch_create
+ *   mj_deleteData         wrapper/core.py:649           dmc_batch_free
+ *   mj_resetData          engine.py:280                 dmc_batch_reset
+ *   np.copyto(qpos/qvel)  suite tasks' initialize_episode dmc_batch_set_state,
+ *                                                       dmc_batch_init_episode
+ *   mj_forward            engine.py:305 (after_reset)   dmc_batch_forward
+ *   mj_step2/mj_step +    engine.py:162-166             dmc_batch_step
+ *     mj_step1
+ *   mjData field views    wrapper/core.py:630-776       dmc_batch_read,
+ *                                                       dmc_batch_device_ptr
+ *   mj_copyData           engine.py:262                 dmc_batch_copy_state
+ *
+ * (*) MJCF parsing/compilation is host logic in Python
+ *     (dm_control_amd/mjcf/compiler.py); what crosses the ABI is the gfx950
+ *     code object specialised for that model (dm_control_amd/codegen.py).
+ */
+#ifndef DMC_HIP_H_
+#define DMC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dmc_model dmc_model;
+typedef struct dmc_batch dmc_batch;
+
+/* fields addressable through dmc_batch_read / dmc_batch_device_ptr */
+enum dmc_field {
+  DMC_FIELD_QPOS = 0,       /* real [nq][nenv] */
+  DMC_FIELD_QVEL = 1,       /* real [nv][nenv] */
+  DMC_FIELD_WARMSTART = 2,  /* real [nv][nenv]  (qacc_warmstart) */
+  DMC_FIELD_TIME = 3,       /* real [nenv] */
+  DMC_FIELD_CTRL = 4,       /* real [nu][nenv]  (last applied data.ctrl) */
+  DMC_FIELD_OBS = 5,        /* real [nenv][nobs] (row-major, agent layout) */
+  DMC_FIELD_REWARD = 6,     /* real [nenv] */
+  DMC_FIELD_SENSORDATA = 7, /* real [nsensordata][nenv] */
+  DMC_FIELD_XPOS = 8,       /* real [nbody*3][nenv] */
+  DMC_FIELD_XMAT = 9,       /* real [nbody*9][nenv] */
+  DMC_FIELD_QACC = 10,      /* real [nv][nenv] */
+  DMC_FIELD_WARN = 11,      /* uint32 [nenv] sticky mjtWarning bit mask */
+  DMC_FIELD_STATS = 12,     /* int32 [3][nenv]: ncon, nefc, solver iterations */
+  DMC_FIELD_RETURN = 13,    /* real [nenv] sum of rewards since the last reset */
+  DMC_FIELD_COUNT = 14
+};
+
+enum dmc_warn_bit {
+  DMC_WARN_INERTIA = 1, DMC_WARN_CONTACTFULL = 2, DMC_WARN_CNSTRFULL = 4,
+  DMC_WARN_VGEOMFULL = 8, DMC_WARN_BADQPOS = 16, DMC_WARN_BADQVEL = 32,
+  DMC_WARN_BADQACC = 64, DMC_WARN_BADCTRL = 128
+};
+
+/* sizes of a loaded model (read back from the code object) */
+typedef struct dmc_model_info {
+  int abi, real_size, nq, nv, nu, nbody, nobs, nsensordata, ws_per_env, task,
+      ncon_max, nefc_max, integrator, npair;
+} dmc_model_info;
+
+int dmc_version(void);
+const char* dmc_last_error(void);
+int dmc_device_count(void);
+
+/* model = gfx950 code object specialised for one compiled MJCF */
+int dmc_model_load(const char* code_object_path, int device_id, dmc_model** out);
+int dmc_model_get_info(const dmc_model* model, dmc_model_info* info);
+void dmc_model_free(dmc_model* model);
+
+/* batch of nenv instances resident in the HBM of the model's device */
+int dmc_batch_create(const dmc_model* model, int nenv, dmc_batch** out);
+void dmc_batch_free(dmc_batch* batch);
+int dmc_batch_nenv(const dmc_batch* batch);
+
+/* task parameters: integer flags + up to 4 reals (meaning is per task, e.g.
+ * cartpole {bit0 sparse, bit1 swing_up}; humanoid r[0] = move_speed) */
+int dmc_batch_set_task_params(dmc_batch* batch, int iparam, const double* rparam,
+                              int nr);
+
+/* mj_resetData for every env: qpos <- qpos0, qvel/ctrl/warmstart/time <- 0,
+ * warning mask cleared */
+int dmc_batch_reset(dmc_batch* batch);
+/* explicit state upload, host pointers, `real`-typed [k][nenv]; NULL = keep */
+int dmc_batch_set_state(dmc_batch* batch, const void* qpos, const void* qvel,
+                        const void* warmstart, const void* time);
+/* task.initialize_episode on device (counter-based RNG keyed by seed, env).
+ * only_colliding != 0 redraws only envs whose last contact count was > 0. */
+int dmc_batch_init_episode(dmc_batch* batch, uint64_t seed, int only_colliding);
+/* position/velocity stage + observation/reward/sensors of the current state
+ * (what the task reads after reset_context; count_contacts != 0 also runs the
+ * narrowphase so DMC_FIELD_STATS[0] = ncon) */
+int dmc_batch_forward(dmc_batch* batch, int count_contacts);
+
+/* nsub x Physics.step, then observation + reward.
+ * ctrl: element (k, env) at ctrl[k*stride_k + env*stride_env] (in reals);
+ * host pointer when on_device == 0 (copied), device pointer otherwise
+ * (zero-copy, e.g. a torch tensor).  ctrl == NULL keeps the previous control.
+ * want_outputs == 0 skips observation/reward (settle steps). */
+int dmc_batch_step(dmc_batch* batch, const void* ctrl, long long stride_k,
+                   long long stride_env, int on_device, int nsub,
+                   int want_outputs);
+
+/* device -> host copy of a whole field (synchronises the batch stream) */
+int dmc_batch_read(dmc_batch* batch, int field, void* dst, size_t bytes);
+size_t dmc_batch_field_bytes(const dmc_batch* batch, int field);
+/* borrowed device pointer; lifetime = the batch handle */
+void* dmc_batch_device_ptr(dmc_batch* batch, int field);
+int dmc_batch_clear_warnings(dmc_batch* batch);
+int dmc_batch_copy_state(dmc_batch* dst, const dmc_batch* src);
+int dmc_batch_sync(dmc_batch* batch);
+/* the batch's hipStream_t, for callers that enqueue their own work behind the
+ * step (e.g. torch.cuda.ExternalStream) */
+void* dmc_batch_stream(dmc_batch* batch);
+
+/* timing of the step kernel on the batch's own stream (HIP events around the
+ * launches issued since dmc_batch_timer_start); returns accumulated device
+ * milliseconds and the number of launches */
+int dmc_batch_timer_start(dmc_batch* batch);
+int dmc_batch_timer_stop(dmc_batch* batch, double* ms, long long* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* DMC_HIP_H_ */

@@ -1,0 +1,55 @@
+"""Shared helpers for the parity tests (oracle = checker, HIP path = product)."""
+
+import os
+
+import numpy as np
+
+from dm_control_amd import codegen
+from dm_control_amd.mjcf import compiler
+
+MODELS_DIR = os.path.join(os.path.dirname(os.path.dirname(
+    os.path.abspath(__file__))), 'dm_control_amd', 'suite', 'models')
+TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
+         'humanoid': codegen.TASK_HUMANOID}
+
+
+def load_model(name):
+  return compiler.from_xml_path(os.path.join(MODELS_DIR, name + '.xml'))
+
+
+def initial_states(model, name, nenv, seed):
+  """Plausible, contact-rich initial states [nenv, nq], [nenv, nv]."""
+  rs = np.random.RandomState(seed)
+  qpos = np.tile(model.qpos0, (nenv, 1))
+  qvel = np.zeros((nenv, model.nv))
+  if name == 'cartpole':
+    qpos[:, 0] = rs.uniform(-1.0, 1.0, nenv)
+    qpos[:, 1] = rs.uniform(-np.pi, np.pi, nenv)
+    qvel[:] = rs.randn(nenv, model.nv)
+  elif name == 'cheetah':
+    lim = model.jnt_limited.astype(bool)
+    lo, hi = model.jnt_range[lim].T
+    qpos[:, lim] = rs.uniform(lo, hi, (nenv, lim.sum()))
+    qpos[:, 1] = rs.uniform(-0.1, 0.3, nenv)
+    qpos[:, 2] = rs.uniform(-0.5, 0.5, nenv)
+    qvel[:] = 0.5*rs.randn(nenv, model.nv)
+  elif name == 'humanoid':
+    for j in range(model.njnt):
+      if model.jnt_limited[j]:
+        a = model.jnt_qposadr[j]
+        lo, hi = model.jnt_range[j]
+        qpos[:, a] = rs.uniform(0.5*lo, 0.5*hi, nenv)
+    quat = rs.randn(nenv, 4)*0.3 + np.array([1.0, 0, 0, 0])
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    qpos[:, 3:7] = quat
+    qpos[:, 2] = rs.uniform(0.9, 1.5, nenv)
+    qvel[:] = 0.3*rs.randn(nenv, model.nv)
+  return qpos, qvel
+
+
+def rel_err(a, b):
+  """max_i |a_i - b_i| / max(1, max_i |b_i|), per row."""
+  a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+  num = np.max(np.abs(a - b), axis=-1)
+  den = np.maximum(1.0, np.max(np.abs(b), axis=-1))
+  return num/den
