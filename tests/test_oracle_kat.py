@@ -1,0 +1,261 @@
+"""The CPU oracle against the reference's own known-answer tests.
+
+These pin oracle/mjstep.c -- the checker of the HIP path -- to every number the
+reference tree holds for the libmujoco boundary.  No GPU needed.
+"""
+
+import math
+
+import numpy as np
+import pytest
+import scipy.linalg
+
+import kat_models
+from dm_control_amd.mjcf import compiler
+from dm_control_amd.mjcf import model as mdl
+from oracle import oracle
+
+
+def _physics(xml):
+  return oracle.OraclePhysics.from_xml_string(xml)
+
+
+def test_k1_readme_box_rests_at_published_height():
+  """mujoco/README.md:29-49: geom z after 1 s == [0.19996362 0.39996362]."""
+  p = _physics(kat_models.README_BOX)
+  p.reset()
+  p.data.qpos[0] = 0.5
+  p.after_reset()
+  np.testing.assert_allclose(p.data.geom_xpos[1:, 2], [0.8, 1.0], atol=1e-12)
+  while p.time() < 1.:
+    p.step()
+  z = p.data.geom_xpos[1:, 2]
+  assert ['%.8f' % v for v in z] == ['0.19996362', '0.39996362']
+
+
+def test_k2_cube_settles_and_disable_flags():
+  """wrapper/core_test.py:328-368.
+
+  The reference reads a touch sensor whose site covers the cube; its reading is
+  the sum of the contact normal forces inside the site, which is what is
+  summed here.
+  """
+  p = _physics(kat_models.CUBE_ON_FLOOR)
+  for _ in range(100):
+    p.data.step()
+  assert abs(p.data.qvel[0]) < 0.5e-4
+  touch = sum(p.data.contact_force(i)[0, 0] for i in range(p.data.ncon))
+  assert abs(touch - 9.81) < 0.005
+  flags = p.omodel.get_int('disableflags')
+  p.omodel.set_int('disableflags', flags | mdl.DSBL_CONTACT | mdl.DSBL_GRAVITY)
+  p.data.step()
+  assert abs(p.data.qvel[0]) < 0.5e-4
+  assert p.data.ncon == 0
+  p.omodel.set_int('disableflags', flags | mdl.DSBL_CONTACT)
+  for _ in range(10):
+    p.data.step()
+  assert p.data.qvel[0] < -0.1
+
+
+def test_k3_contact_normal_force_equals_weight():
+  """wrapper/core_test.py:461-484: 7 decimal places after 500 steps."""
+  p = _physics(kat_models.BOX_ON_FLOOR)
+  for _ in range(500):
+    p.data.step()
+  normal = sum(p.data.contact_force(i)[0, 0] for i in range(p.data.ncon))
+  weight = 9.81*p.model.body_mass[1]
+  assert p.data.ncon == 4
+  assert abs(normal - weight) < 0.5e-7
+  with pytest.raises(ValueError):
+    p.data.contact_force(p.data.ncon)
+  with pytest.raises(ValueError):
+    p.data.contact_force(-1)
+
+
+@pytest.mark.parametrize('qpos,expected_lin,local', [
+    ([0., 0.], [1.5, 0., 0.], False),
+    ([0., np.pi], [0.5, 0., 0.], False),
+    ([0., np.pi], [-0.5, 0., 0.], True),
+])
+def test_k4_object_velocity(qpos, expected_lin, local):
+  """wrapper/core_test.py:407-459 (tip of a cart-pole, qvel = [1, 1])."""
+  p = _physics(kat_models.CART_POINT_MASS)
+  p.data.qpos[:] = qpos
+  p.data.qvel[:] = [1., 1.]
+  p.data.step1()
+  gid = p.model.name2id('mass', 'geom')
+  lin, ang = p.data.point_velocity(p.model.geom_bodyid[gid],
+                                   p.data.geom_xpos[gid])
+  if local:
+    rot = p.data.geom_xmat[gid].reshape(3, 3)
+    lin, ang = rot.T @ lin, rot.T @ ang
+  np.testing.assert_array_almost_equal(lin, expected_lin)
+  np.testing.assert_array_almost_equal(ang, [0., 1., 0.])
+
+
+@pytest.mark.parametrize('condim,expected', [
+    (3, [False, False, False]), (4, [True, False, False]),
+    (6, [True, True, True])])
+def test_k5_contact_torque_pattern(condim, expected):
+  """wrapper/core_test.py:495-531."""
+  model = compiler.from_xml_string(kat_models.BALL_ON_FLOOR)
+  model.geom_condim[:] = condim
+  p = oracle.OraclePhysics(model)
+  p.data.qvel[3:] = 1.
+  for _ in range(10):
+    p.data.step()
+  assert p.data.ncon == 1
+  torque = p.data.contact_force(0)[1]
+  np.testing.assert_array_equal(torque != 0, expected)
+
+
+def test_k6_reset_forward_dynamics_and_actuation_flag():
+  """engine_test.py:491-504.
+
+  An accelerometer at rest reads -gravity because the body's acceleration is 0
+  while gravity pulls: equivalently a free body after reset has qacc = gravity
+  and a supported one has qacc = 0.  `after_reset` must ignore data.ctrl.
+  """
+  p = _physics(kat_models.BOX_ON_FLOOR)
+  p.reset()
+  # the box starts exactly touching the floor (4 corner contacts at dist 0)
+  np.testing.assert_allclose(p.data.qacc_smooth[2], -9.81, atol=1e-12)
+  cart = oracle.OraclePhysics.from_xml_string(
+      open(__import__('helpers').MODELS_DIR + '/cartpole.xml').read())
+  cart.reset()
+  cart.data.ctrl[0] = 1.
+  cart.after_reset()
+  assert cart.data.actuator_force[0] == 0.
+  cart.forward()
+  assert cart.data.actuator_force[0] == 1.
+
+
+def _lqr_model(n_bodies, n_actuators, random):
+  """Spring chain of suite/lqr.py:140-200 (tendons there are visual only)."""
+  xml = ['<mujoco><option timestep=".03"><flag constraint="disable"/></option>'
+         '<default><joint type="slide" axis="0 1 0"/>'
+         '<geom type="sphere" size=".1"/></default><worldbody>'
+         '<geom name="floor" size="4 1 .2" type="plane"/>']
+  for b in range(n_bodies):
+    pos = '.25 0 .1' if b == 0 else '.25 0 0'
+    k = random.uniform(15, 25)
+    d = random.uniform(0, 0)
+    xml.append('<body name="body_%d" pos="%s"><joint name="joint_%d" '
+               'stiffness="%r" damping="%r"/><geom name="geom_%d"/>'
+               % (b, pos, b, k, d, b))
+  xml.append('</body>'*n_bodies)
+  xml.append('</worldbody><actuator>')
+  for b in range(n_actuators):
+    xml.append('<motor name="motor_%d" joint="joint_%d"/>' % (b, b))
+  xml.append('</actuator></mujoco>')
+  return ''.join(xml)
+
+
+@pytest.mark.parametrize('n_bodies,n_actuators', [(2, 1), (6, 2)])
+def test_k7_lqr_cost_matches_riccati(n_bodies, n_actuators):
+  """suite/lqr_test.py:28-59 with suite/lqr_solver.py:28-81, rtol 1e-3."""
+  rs = np.random.RandomState(0)
+  p = _physics(_lqr_model(n_bodies, n_actuators, rs))
+  m = p.model
+  n, nu, dt, coef = m.nq, m.nu, m.opt.timestep, 0.1
+  p.reset()
+  mass = p.data.qM.copy()
+  stiffness = np.diag(m.jnt_stiffness)
+  damping = np.diag(m.dof_damping)
+  j = np.linalg.solve(-mass, np.hstack((stiffness, damping)))
+  a = np.eye(2*n) + dt*np.vstack(
+      (dt*j + np.hstack((np.zeros((n, n)), np.eye(n))), j))
+  moment = np.zeros((nu, n))
+  for i in range(nu):
+    moment[i, m.jnt_dofadr[m.actuator_trnid[i]]] = m.actuator_gear[i]
+  bc = np.linalg.solve(mass, moment.T)
+  b = dt*np.vstack((dt*bc, bc))
+  q = np.diag(np.hstack([np.ones(n), np.zeros(n)]))
+  r = coef*np.eye(nu)
+  pmat = scipy.linalg.solve_discrete_are(a, b, q, r)
+  k = -np.linalg.solve(b.T @ pmat @ b + r, b.T @ pmat @ a)
+  beta = np.abs(np.linalg.eigvals(a + b @ k)).max()
+  assert beta < 1.0
+  n_steps = int(math.ceil(math.log10(1e-3)/math.log10(beta)))
+  unit = rs.randn(n)
+  p.reset()
+  p.data.qpos[:] = np.sqrt(2)*unit/np.linalg.norm(unit)
+  p.after_reset()
+  x0 = np.hstack((p.data.qpos, p.data.qvel))
+  total, reward = 0.0, None
+  for _ in range(n_steps):
+    x = np.hstack((p.data.qpos, p.data.qvel))
+    u = k @ x
+    total += 1 - (reward or 0.0)
+    p.set_control(u)
+    p.step()
+    reward = 1 - (0.5*p.data.qpos @ p.data.qpos + 0.5*coef*(u @ u))
+  np.testing.assert_allclose(0.5*x0 @ pmat @ x0, total, rtol=1e-3)
+
+
+def test_k8_bitwise_determinism_and_reset():
+  """suite/suite_test.py:169-185 on the oracle: same inputs, same bits."""
+  import helpers
+  for name in ('cartpole', 'cheetah', 'humanoid'):
+    m = helpers.load_model(name)
+    runs = []
+    for _ in range(2):
+      p = oracle.OraclePhysics(m)
+      p.reset()
+      rs = np.random.RandomState(3)
+      for _ in range(50):
+        p.set_control(rs.uniform(-1, 1, m.nu))
+        p.step()
+      runs.append((p.data.qpos.copy(), p.data.qvel.copy()))
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert np.array_equal(runs[0][1], runs[1][1])
+    assert not p.data.warning.any()
+
+
+def test_k9_cartpole_sizes():
+  """engine_test.py:331-338."""
+  import helpers
+  m = helpers.load_model('cartpole')
+  assert (m.nu, m.nq, m.nv) == (1, 2, 2)
+  assert m.opt.timestep == 0.01
+  p = oracle.OraclePhysics(m)
+  assert p.time() == 0.
+
+
+def test_bad_state_sets_warning_and_resets():
+  """engine_test.py:400-436: divergence is reported through the warning
+  counters (mjWARN_BADQPOS / BADQACC), the data is reset to qpos0."""
+  import helpers
+  m = helpers.load_model('cartpole')
+  p = oracle.OraclePhysics(m)
+  p.reset()
+  p.data.qpos[0] = np.nan
+  p.step()
+  assert p.data.warning[4] == 1          # mjWARN_BADQPOS
+  np.testing.assert_array_equal(p.data.qpos, m.qpos0)
+  p.data.ctrl[0] = np.nan
+  p.step()
+  assert p.data.warning[6] >= 1          # mjWARN_BADQACC
+
+
+def test_cartpole_energy_is_conserved_by_rk4():
+  """with damping and actuation off RK4 keeps the
+  mechanical energy of the cart-pole to O(h^4)."""
+  import helpers
+  m = helpers.load_model('cartpole')
+  m.dof_damping[:] = 0
+  p = oracle.OraclePhysics(m)
+  p.reset()
+  p.data.qpos[:] = [0.1, 2.0]
+  p.data.qvel[:] = [0.3, -1.0]
+  p.after_reset()
+
+  def energy():
+    v = p.data.qvel
+    kin = 0.5*v @ p.data.qM @ v
+    pot = sum(9.81*m.body_mass[b]*p.data.xipos[b, 2] for b in range(m.nbody))
+    return kin + pot
+  e0 = energy()
+  for _ in range(500):
+    p.step()
+  assert abs(energy() - e0) < 1e-7*abs(e0) + 1e-7
