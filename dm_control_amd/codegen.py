@@ -278,6 +278,33 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   tr('pair_friction', pair_fric); tr('pair_K', pair_k); tr('pair_B', pair_b)
   tr('pair_solimp', pair_solimp); tr('pair_diag', pair_diag)
   ti('task_body', (task_bodies(m, task) + [0]*6)[:6])
+  # static ancestor chains (replace pointer-chasing loops over dof_parentid so
+  # that fully unrolled code indexes per-lane arrays with compile-time indices)
+  chains = []
+  for b in range(m.nbody):
+    bb = b
+    while bb > 0 and m.body_dofnum[bb] == 0:
+      bb = int(m.body_parentid[bb])
+    chain = []
+    if bb > 0:
+      d = int(m.body_dofadr[bb] + m.body_dofnum[bb] - 1)
+      while d >= 0:
+        chain.append(d)
+        d = int(m.dof_parentid[d])
+    chains.append(chain)
+  ancs = []
+  for i in range(m.nv):
+    a, d = [], int(m.dof_parentid[i])
+    while d >= 0:
+      a.append(d)
+      d = int(m.dof_parentid[d])
+    ancs.append(a)
+  maxchain = max([1] + [len(c) for c in chains] + [len(a) for a in ancs])
+  ci('MAXCHAIN', maxchain)
+  ti('body_chain_len', [len(c) for c in chains])
+  ti('body_chain', [v for c in chains for v in (c + [0]*maxchain)[:maxchain]])
+  ti('dof_anc_len', [len(a) for a in ancs])
+  ti('dof_anc', [v for a in ancs for v in (a + [0]*maxchain)[:maxchain]])
   w('}  // namespace dmc_model')
   return '\n'.join(out) + '\n'
 

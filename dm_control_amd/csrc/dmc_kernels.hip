@@ -27,11 +27,19 @@
 typedef double real;   // must match dmc_real in the generated header
 #define DMC_TOL_FLOOR 0.0
 #define DMC_MINVAL 1e-15
+#define DMC_F32_RULES 0
 #else
 typedef float real;
 // fp32 cannot resolve cost changes below ~1e-7 relative; see DESIGN.md
 #define DMC_TOL_FLOOR 1e-6
 #define DMC_MINVAL 1e-15f
+// fp32-only stopping rules: the absolute 1e-8-style thresholds of
+// the fp64 algorithm sit below fp32 rounding noise of the cost, so the solver
+// additionally stops (a) the line search once the directional derivative has
+// dropped by 1e-5 relative to its value at alpha = 0 and (b) the Newton loop
+// after a full step (alpha ~ 1) that left the active set unchanged -- at that
+// point the iterate is the exact minimiser of the current quadratic piece.
+#define DMC_F32_RULES 1
 #endif
 
 #ifndef DMC_MODEL_HEADER
@@ -43,7 +51,7 @@ using namespace dmc_model;
 
 #define R(x) ((real)(x))
 #define DEV static __device__ __forceinline__
-#define DEVN static __device__ __noinline__
+#define DEVN static __device__ __forceinline__
 
 constexpr int NM = NV*(NV + 1)/2;      // packed lower triangle
 constexpr int NVX = NV > 0 ? NV : 1;
@@ -226,14 +234,45 @@ struct Env {
   unsigned warn;
 };
 
-struct Work {
-  real* base; long long nenv; int e;
-  __device__ real& J(int r, int j) const { return base[((long long)(r*NV + j))*nenv + e]; }
-  __device__ real& D(int r) const { return base[((long long)(NEFC_MAX*NV + r))*nenv + e]; }
-  __device__ real& aref(int r) const { return base[((long long)(NEFC_MAX*NV + NEFC_MAX + r))*nenv + e]; }
-  __device__ real& jar(int r) const { return base[((long long)(NEFC_MAX*NV + 2*NEFC_MAX + r))*nenv + e]; }
-  __device__ real& jv(int r) const { return base[((long long)(NEFC_MAX*NV + 3*NEFC_MAX + r))*nenv + e]; }
+// Constraint rows: record r = [J(0..NV-1), D, aref, Jaref, Jv].  The first
+// LDS_ROWS records of each lane live in LDS ([record word][lane]: every lane
+// hits its own bank, conflict-free for any per-lane row index); records beyond
+// that spill to the HBM workspace with the same [word][env] layout.
+constexpr int RW = NV + 4;
+#ifndef DMC_LDS_BUDGET
+#define DMC_LDS_BUDGET (128*1024)
+#endif
+constexpr int LDS_ROWS_FIT = DMC_LDS_BUDGET/(RW*64*(int)sizeof(real));
+constexpr int LDS_ROWS = LDS_ROWS_FIT < NEFC_MAX ? LDS_ROWS_FIT : NEFC_MAX;
+enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3 };
+
+struct LdsRow {
+  real* p;
+  __device__ __forceinline__ real get(int k) const { return p[k*64]; }
+  __device__ __forceinline__ void set(int k, real v) const { p[k*64] = v; }
 };
+struct GlbRow {
+  real* p; long long n;
+  __device__ __forceinline__ real get(int k) const { return p[k*n]; }
+  __device__ __forceinline__ void set(int k, real v) const { p[k*n] = v; }
+};
+struct Work {
+  real* lds;   // LDS base + lane
+  real* glb;   // workspace base + env
+  long long nenv;
+  __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*64}; }
+  __device__ __forceinline__ GlbRow grow(int r) const {
+    return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
+  }
+};
+// f(row handle) for rows [0, nefc): LDS tier first, then the HBM tier
+template <class F>
+static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) {
+  const int n1 = nefc < LDS_ROWS ? nefc : LDS_ROWS;
+  for (int r = 0; r < n1; r++) f(W.lrow(r));
+  if (LDS_ROWS < NEFC_MAX)
+    for (int r = LDS_ROWS; r < nefc; r++) f(W.grow(r));
+}
 
 // ---------------------------------------------------------------------------
 // position stage: kinematics, centre-of-mass frame, composite inertia
@@ -395,8 +434,12 @@ DEV void crb_factor(Env& E) {
     real buf[6];
     mul_inert_vec(buf, crb + 10*dof_bodyid[i], E.cdof + 6*i);
     E.qM[tri(i, i)] = dot6(E.cdof + 6*i, buf) + R(dof_armature[i]);
-    for (int j = dof_parentid[i]; j >= 0; j = dof_parentid[j])
-      E.qM[tri(i, j)] = dot6(E.cdof + 6*j, buf);
+    DMC_UNROLL
+    for (int a = 0; a < MAXCHAIN; a++)
+      if (a < dof_anc_len[i]) {
+        const int j = dof_anc[i*MAXCHAIN + a];
+        E.qM[tri(i, j)] = dot6(E.cdof + 6*j, buf);
+      }
   }
   DMC_UNROLL
   for (int i = 0; i < NM; i++) E.qL[i] = E.qM[i];
@@ -543,33 +586,45 @@ DEV real impedance(const real* s, real x) {
 // row[j] += sign * dir . d(point velocity)/d(qvel_j) for a point on `body`
 DEV void add_jac_dir(real* row, const Env& E, int body, const real* point,
                      const real* dir, real sign) {
-  while (body > 0 && body_dofnum[body] == 0) body = body_parentid[body];
-  if (body <= 0) return;
+  if (body_chain_len[body] == 0) return;
   real off[3], w[3];
   const int root = body_rootid[body];
   for (int k = 0; k < 3; k++) off[k] = point[k] - E.subtree_com[3*root + k];
   cross3(w, off, dir);   // dir.(ang x off) = ang.(off x dir)
-  for (int i = body_dofadr[body] + body_dofnum[body] - 1; i >= 0; i = dof_parentid[i]) {
-    const real* cd = E.cdof + 6*i;
-    row[i] += sign*(dot3(dir, cd + 3) + dot3(w, cd));
-  }
+  DMC_UNROLL
+  for (int c = 0; c < MAXCHAIN; c++)
+    if (c < body_chain_len[body]) {
+      const int i = body_chain[body*MAXCHAIN + c];
+      const real* cd = E.cdof + 6*i;
+      row[i] += sign*(dot3(dir, cd + 3) + dot3(w, cd));
+    }
 }
 DEV void add_jac_rot(real* row, const Env& E, int body, const real* dir, real sign) {
-  while (body > 0 && body_dofnum[body] == 0) body = body_parentid[body];
-  if (body <= 0) return;
-  for (int i = body_dofadr[body] + body_dofnum[body] - 1; i >= 0; i = dof_parentid[i])
-    row[i] += sign*dot3(dir, E.cdof + 6*i);
+  DMC_UNROLL
+  for (int c = 0; c < MAXCHAIN; c++)
+    if (c < body_chain_len[body]) {
+      const int i = body_chain[body*MAXCHAIN + c];
+      row[i] += sign*dot3(dir, E.cdof + 6*i);
+    }
 }
 
+template <class Row>
+DEV void write_row(const Row& rec, const Env& E, const real* row, real pm,
+                   real K, real B, real imp, real Rrow) {
+  real vel = 0;
+  DMC_UNROLL
+  for (int j = 0; j < NV; j++) { rec.set(j, row[j]); vel += row[j]*E.qvel[j]; }
+  rec.set(ROW_AREF, -B*vel - K*imp*pm);
+  rec.set(ROW_D, R(1)/(Rrow < DMC_MINVAL ? DMC_MINVAL : Rrow));
+}
 DEV bool push_row(Env& E, const Work& W, const real* row, real pos_minus_margin,
                   real K, real B, real imp, real Rrow) {
   if (E.nefc >= NEFC_MAX) { E.warn |= WARN_CNSTRFULL; return false; }
   const int r = E.nefc++;
-  real vel = 0;
-  DMC_UNROLL
-  for (int j = 0; j < NV; j++) { W.J(r, j) = row[j]; vel += row[j]*E.qvel[j]; }
-  W.aref(r) = -B*vel - K*imp*pos_minus_margin;
-  W.D(r) = R(1)/(Rrow < DMC_MINVAL ? DMC_MINVAL : Rrow);
+  if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS)
+    write_row(W.lrow(r), E, row, pos_minus_margin, K, B, imp, Rrow);
+  else
+    write_row(W.grow(r), E, row, pos_minus_margin, K, B, imp, Rrow);
   return true;
 }
 
@@ -762,6 +817,7 @@ DEV int collide_pair(const Env& E, int p, RawCon* rc) {
 
 DEVN void contact_rows(Env& E, const Work& W) {
   if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return;
+  DMC_UNROLL
   for (int p = 0; p < NPAIR; p++) {
     RawCon rc[4];
     const int n = collide_pair(E, p, rc);
@@ -824,23 +880,24 @@ struct LsPoint { real alpha, dcost, d0, d1; };
 DEV void ls_eval(LsPoint& P, real alpha, const Env& E, const Work& W, real q1, real q2) {
   real dcost = alpha*alpha*q2 + alpha*q1;
   real d0 = 2*alpha*q2 + q1, d1 = 2*q2;
-  for (int r = 0; r < E.nefc; r++) {
-    const real x0 = W.jar(r), v = W.jv(r), D = W.D(r);
+  for_rows(W, E.nefc, [&](auto rec) {
+    const real x0 = rec.get(ROW_JAR), v = rec.get(ROW_JV), D = rec.get(ROW_D);
     const real x = x0 + alpha*v;
     const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
     dcost += R(0.5)*D*(a*a - a0*a0);
     if (x < 0) { d0 += D*x*v; d1 += D*v*v; }
-  }
+  });
   P.alpha = alpha; P.dcost = dcost; P.d0 = d0;
   P.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
 }
 
-DEVN void solve_newton(Env& E, const Work& W, real tol) {
+DEV void solve_newton(Env& E, const Work& W, real tol) {
   real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], H[NM > 0 ? NM : 1];
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
   symv(Ma, E.qM, E.qacc);
   real improvement = 0;
+  bool converged = false;
   int iter = 0;
   for (;; iter++) {
     // active set, forces, gradient and Hessian in one pass over the rows
@@ -848,13 +905,13 @@ DEVN void solve_newton(Env& E, const Work& W, real tol) {
     for (int i = 0; i < NM; i++) H[i] = E.qM[i];
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
-    for (int r = 0; r < nefc; r++) {
-      const real jar = W.jar(r);
+    for_rows(W, nefc, [&](auto rec) {
+      const real jar = rec.get(ROW_JAR);
       if (jar < 0) {
-        const real D = W.D(r), f = -D*jar;
+        const real D = rec.get(ROW_D), f = -D*jar;
         real row[NVX];
         DMC_UNROLL
-        for (int j = 0; j < NV; j++) row[j] = W.J(r, j);
+        for (int j = 0; j < NV; j++) row[j] = rec.get(j);
         DMC_UNROLL
         for (int j = 0; j < NV; j++) {
           E.qfrc_constraint[j] += row[j]*f;
@@ -863,14 +920,14 @@ DEVN void solve_newton(Env& E, const Work& W, real tol) {
           for (int k = 0; k <= j; k++) H[tri(j, k)] += s*row[k];
         }
       }
-    }
+    });
     real gn = 0;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) {
       grad[i] = Ma[i] - E.qfrc_smooth[i] - E.qfrc_constraint[i];
       gn += grad[i]*grad[i];
     }
-    if (iter > 0 && (scale*improvement < tol || scale*sqrt(gn) < tol)) break;
+    if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
     chol_factor(H);
     DMC_UNROLL
@@ -889,12 +946,12 @@ DEVN void solve_newton(Env& E, const Work& W, real tol) {
       q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
       q2 += R(0.5)*search[i]*Mv[i];
     }
-    for (int r = 0; r < nefc; r++) {
-      real s = 0;
+    for_rows(W, nefc, [&](auto rec) {
+      real sacc = 0;
       DMC_UNROLL
-      for (int j = 0; j < NV; j++) s += W.J(r, j)*search[j];
-      W.jv(r) = s;
-    }
+      for (int j = 0; j < NV; j++) sacc += rec.get(j)*search[j];
+      rec.set(ROW_JV, sacc);
+    });
     // exact line search: safeguarded Newton on the directional derivative
     LsPoint p0, p, best;
     ls_eval(p0, 0, E, W, q1, q2);
@@ -902,10 +959,11 @@ DEVN void solve_newton(Env& E, const Work& W, real tol) {
     best = p0;
     real lo = 0, hi = 0, a = -p0.d0/p0.d1;
     bool have_hi = false;
-    for (int it = 0; it < 50; it++) {
+    const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
+    for (int it = 0; it < (DMC_F32_RULES ? 20 : 50); it++) {
       ls_eval(p, a, E, W, q1, q2);
       if (p.dcost < best.dcost) best = p;
-      if (fabs(p.d0) < gtol) break;
+      if (fabs(p.d0) < dtol) break;
       if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
       real an = a - p.d0/p.d1;
       if (have_hi) {
@@ -921,7 +979,16 @@ DEVN void solve_newton(Env& E, const Work& W, real tol) {
     improvement = -best.dcost;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) { E.qacc[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
-    for (int r = 0; r < nefc; r++) W.jar(r) += alpha*W.jv(r);
+    bool changed = false;
+    for_rows(W, nefc, [&](auto rec) {
+      const real x0 = rec.get(ROW_JAR);
+      const real x1 = x0 + alpha*rec.get(ROW_JV);
+      changed |= (x0 < 0) != (x1 < 0);
+      rec.set(ROW_JAR, x1);
+    });
+    // qfrc_constraint must be refreshed for the final iterate: flag and let the
+    // next pass over the rows run before leaving
+    if (DMC_F32_RULES && !changed && fabs(alpha - 1) < R(1e-3)) converged = true;
   }
   E.iters = iter;
 }
@@ -942,45 +1009,37 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qacc[i] = E.qacc_smooth[i];
   } else {
-    // warmstart: better of previous qacc and the unconstrained acceleration
-    bool use_warm = false;
-    if (!(DISABLEFLAGS & DSBL_WARMSTART)) {
-      real Ma[NVX], cw = 0, cs = 0;
+    // warmstart: better of previous qacc and the unconstrained acceleration;
+    // Jaref of both candidates in one pass (warm -> ROW_JAR, smooth -> ROW_JV)
+    const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
+    real Ma[NVX], cw = 0, cs = 0;
+    if (try_warm) {
       symv(Ma, E.qM, E.warm);
       DMC_UNROLL
       for (int i = 0; i < NV; i++)
         cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
-      for (int r = 0; r < E.nefc; r++) {
-        real jw = 0, js = 0;
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) {
-          const real v = W.J(r, j);
-          jw += v*E.warm[j]; js += v*E.qacc_smooth[j];
-        }
-        const real aref = W.aref(r), D = W.D(r);
-        jw -= aref; js -= aref;
-        if (jw < 0) cw += R(0.5)*D*jw*jw;
-        if (js < 0) cs += R(0.5)*D*js*js;
-        W.jar(r) = jw; W.jv(r) = js;
-      }
-      use_warm = !(cw > cs);
     }
+    for_rows(W, E.nefc, [&](auto rec) {
+      real jw = 0, js = 0;
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) {
+        const real v = rec.get(j);
+        jw += v*E.warm[j]; js += v*E.qacc_smooth[j];
+      }
+      const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
+      jw -= aref; js -= aref;
+      if (jw < 0) cw += R(0.5)*D*jw*jw;
+      if (js < 0) cs += R(0.5)*D*js*js;
+      rec.set(ROW_JAR, jw); rec.set(ROW_JV, js);
+    });
+    const bool use_warm = try_warm && !(cw > cs);
     if (use_warm) {
       DMC_UNROLL
       for (int i = 0; i < NV; i++) E.qacc[i] = E.warm[i];
     } else {
       DMC_UNROLL
       for (int i = 0; i < NV; i++) E.qacc[i] = E.qacc_smooth[i];
-      if (DISABLEFLAGS & DSBL_WARMSTART) {
-        for (int r = 0; r < E.nefc; r++) {
-          real js = 0;
-          DMC_UNROLL
-          for (int j = 0; j < NV; j++) js += W.J(r, j)*E.qacc_smooth[j];
-          W.jar(r) = js - W.aref(r);
-        }
-      } else {
-        for (int r = 0; r < E.nefc; r++) W.jar(r) = W.jv(r);
-      }
+      for_rows(W, E.nefc, [&](auto rec) { rec.set(ROW_JAR, rec.get(ROW_JV)); });
     }
     solve_newton(E, W, tol);
   }
@@ -1256,7 +1315,7 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate) {
 
 // nsub x Physics.step, then observation + reward of the new state.
 // flags bit0: ctrl given (else reuse ctrl_store); bit1: skip outputs (settle)
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 1)
 dmc_step(DmcArgs a) {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= a.nenv) return;
@@ -1278,7 +1337,8 @@ dmc_step(DmcArgs a) {
   } else {
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
-  Work W = {a.ws, n, e};
+  __shared__ real lds_rows[(LDS_ROWS > 0 ? LDS_ROWS : 1)*RW*64];
+  Work W = {lds_rows + threadIdx.x, a.ws + e, n};
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
   for (int s = 0; s < a.nsub; s++) physics_step(E, W, time, tol);
   if (a.qacc) for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];
@@ -1290,7 +1350,7 @@ dmc_step(DmcArgs a) {
 }
 
 // observation / reward / sensors of the current state (reset, after_reset)
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(64, 1)
 dmc_observe(DmcArgs a) {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= a.nenv) return;
@@ -1301,7 +1361,8 @@ dmc_observe(DmcArgs a) {
   for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   observe_stage(E, time);
   if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
-    Work W = {a.ws, n, e};
+    __shared__ real lds_rows[(LDS_ROWS > 0 ? LDS_ROWS : 1)*RW*64];
+    Work W = {lds_rows + threadIdx.x, a.ws + e, n};
     E.ncon = 0; E.nefc = 0;
     if (NPAIR > 0) contact_rows(E, W);
   }
@@ -1381,5 +1442,5 @@ dmc_init_episode(DmcArgs a) {
 // self-description read by dmc_api.cpp through hipModuleGetGlobal
 extern "C" __device__ const int dmc_info[16] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
-    NEFC_MAX*(NV + 4) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
+    (NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 1)*RW /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
     INTEGRATOR, NPAIR, 0, 0};
