@@ -45,11 +45,12 @@ def build_library(force=False):
   return LIB_PATH
 
 
-def model_key(model, task, precision, ncon_max=None):
+def model_key(model, task, precision, ncon_max=None, extra_flags=()):
   src = os.path.join(_CSRC, 'dmc_kernels.hip')
   h = hashlib.sha1()
   h.update(model.content_hash().encode())
-  h.update(('%d/%s/%r' % (task, precision, ncon_max)).encode())
+  h.update(('%d/%s/%r/%r' % (task, precision, ncon_max,
+                             tuple(extra_flags))).encode())
   for path in (src, os.path.join(_CSRC, 'dmc_args.h'),
                codegen.__file__):
     with open(path, 'rb') as f:
@@ -58,13 +59,13 @@ def model_key(model, task, precision, ncon_max=None):
 
 
 def code_object_path(model, task=codegen.TASK_NONE, precision='f32',
-                     ncon_max=None):
-  return os.path.join(
-      _BUILD, 'dmc_%s.hsaco' % model_key(model, task, precision, ncon_max))
+                     ncon_max=None, extra_flags=()):
+  return os.path.join(_BUILD, 'dmc_%s.hsaco' % model_key(
+      model, task, precision, ncon_max, extra_flags))
 
 
 def build_model(model, task=codegen.TASK_NONE, precision='f32',
-                ncon_max=None, force=False, keep_temps=False):
+                ncon_max=None, force=False, keep_temps=False, extra_flags=None):
   """Generates the constants header for `model` and compiles its kernels.
 
   Returns the path of the gfx950 code object.  Built lazily and cached by
@@ -73,19 +74,34 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
   if precision not in ('f32', 'f64'):
     raise ValueError('precision must be "f32" or "f64"')
   os.makedirs(_BUILD, exist_ok=True)
-  out = code_object_path(model, task, precision, ncon_max)
+  if extra_flags is None:
+    # experiment hook: extra -D flags for ablation builds (never set in tests)
+    extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
+  out = code_object_path(model, task, precision, ncon_max, extra_flags)
   if os.path.exists(out) and not force:
     return out
   key = os.path.basename(out)[4:-6]
   header = os.path.join(_BUILD, 'model_%s.h' % key)
   with open(header, 'w') as f:
     f.write(codegen.generate_header(model, task, ncon_max))
+  # -pragma-unroll-threshold: the per-model straight-line code is far beyond
+  #   LLVM's default budget; without it the pair loop stays rolled, per-lane
+  #   arrays are indexed dynamically and the whole working set lands in scratch.
+  # -fno-slp-vectorize: v_pk_*_f32 is not faster on gfx950 and the packing
+  #   moves cost ~25 % extra instructions plus spills.
+  # -fno-hip-fp32-correctly-rounded-divide-sqrt (fp32 build only): v_rcp/v_rsq
+  #   based division and sqrt (<= 2.5 ulp) instead of the 10-instruction
+  #   IEEE sequences; the fp64 build keeps exact division.
   cmd = [_hipcc(), '--genco', '--offload-arch=' + ARCH, '-O3', '-std=c++17',
+         '-mllvm', '-pragma-unroll-threshold=10000000', '-fno-slp-vectorize',
          '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast',
          '-DDMC_MODEL_HEADER="%s"' % header, '-I', _CSRC,
          '-o', out + '.tmp', os.path.join(_CSRC, 'dmc_kernels.hip')]
+  cmd[1:1] = list(extra_flags)
   if precision == 'f64':
     cmd.insert(1, '-DDMC_REAL_IS_DOUBLE')
+  else:
+    cmd.insert(1, '-fno-hip-fp32-correctly-rounded-divide-sqrt')
   if keep_temps:
     cmd[1:1] = ['-save-temps', '-Rpass-analysis=kernel-resource-usage']
   try:

@@ -178,7 +178,8 @@ DEV void symv(real* y, const real* A, const real* x) {
     y[i] = s;
   }
 }
-// in-place packed Cholesky A = L L^T; returns number of clamped pivots
+// in-place packed Cholesky A = L L^T; the diagonal slots hold 1/L_jj so the
+// triangular solves multiply instead of divide; returns clamped pivots
 DEV int chol_factor(real* A) {
   int nbad = 0;
   DMC_UNROLL
@@ -187,8 +188,8 @@ DEV int chol_factor(real* A) {
     DMC_UNROLL
     for (int k = 0; k < j; k++) s -= A[tri(j, k)]*A[tri(j, k)];
     if (!(s >= DMC_MINVAL)) { s = DMC_MINVAL; nbad++; }
-    real inv = rsqrt_(s);
-    A[tri(j, j)] = s*inv;
+    const real inv = rsqrt_(s);
+    A[tri(j, j)] = inv;
     DMC_UNROLL
     for (int i = j + 1; i < NV; i++) {
       real t = A[tri(i, j)];
@@ -205,14 +206,14 @@ DEV void chol_solve(real* x, const real* L) {
     real s = x[i];
     DMC_UNROLL
     for (int k = 0; k < i; k++) s -= L[tri(i, k)]*x[k];
-    x[i] = s/L[tri(i, i)];
+    x[i] = s*L[tri(i, i)];
   }
   DMC_UNROLL
   for (int i = NV - 1; i >= 0; i--) {
     real s = x[i];
     DMC_UNROLL
     for (int k = i + 1; k < NV; k++) s -= L[tri(k, i)]*x[k];
-    x[i] = s/L[tri(i, i)];
+    x[i] = s*L[tri(i, i)];
   }
 }
 
@@ -281,7 +282,9 @@ DEV void kinematics(Env& E) {
   E.xpos[0] = E.xpos[1] = E.xpos[2] = 0;
   E.xquat[0] = 1; E.xquat[1] = E.xquat[2] = E.xquat[3] = 0;
   quat2mat(E.xmat, E.xquat);
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) E.xipos[k] = 0;
+  DMC_UNROLL
   for (int k = 0; k < 9; k++) E.ximat[k] = E.xmat[k];
   DMC_UNROLL
   for (int i = 1; i < NBODY; i++) {
@@ -289,9 +292,12 @@ DEV void kinematics(Env& E) {
     const int jadr = body_jntadr[i], jnum = body_jntnum[i];
     if (jnum == 1 && jnt_type[jadr < 0 ? 0 : jadr] == JNT_FREE) {
       const int qa = jnt_qposadr[jadr];
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) xpos[k] = E.qpos[qa + k];
+      DMC_UNROLL
       for (int k = 0; k < 4; k++) xquat[k] = E.qpos[qa + 3 + k];
       normalize4(xquat);
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) {
         E.xanchor[3*jadr + k] = xpos[k];
         E.xaxis[3*jadr + k] = R(jnt_axis[3*jadr + k]);
@@ -303,8 +309,10 @@ DEV void kinematics(Env& E) {
                     R(body_quat[4*i + 2]), R(body_quat[4*i + 3])};
       real v[3];
       mulmatvec3(v, E.xmat + 9*pid, bp);
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) xpos[k] = E.xpos[3*pid + k] + v[k];
       mulquat(xquat, E.xquat + 4*pid, bq);
+      DMC_UNROLL
       for (int j = 0; j < jnum; j++) {
         const int jid = jadr + j, qa = jnt_qposadr[jid];
         real jax[3] = {R(jnt_axis[3*jid]), R(jnt_axis[3*jid + 1]), R(jnt_axis[3*jid + 2])};
@@ -313,27 +321,34 @@ DEV void kinematics(Env& E) {
         real* axis = E.xaxis + 3*jid;
         rotvecquat(axis, jax, xquat);
         rotvecquat(anchor, jp, xquat);
+        DMC_UNROLL
         for (int k = 0; k < 3; k++) anchor[k] += xpos[k];
         if (jnt_type[jid] == JNT_SLIDE) {
           real q = E.qpos[qa] - R(qpos0[qa]);
+          DMC_UNROLL
           for (int k = 0; k < 3; k++) xpos[k] += axis[k]*q;
         } else if (jnt_type[jid] == JNT_HINGE || jnt_type[jid] == JNT_BALL) {
           real qloc[4], r[4], vec[3];
           if (jnt_type[jid] == JNT_BALL) {
+            DMC_UNROLL
             for (int k = 0; k < 4; k++) qloc[k] = E.qpos[qa + k];
             normalize4(qloc);
           } else {
             axisangle2quat(qloc, jax, E.qpos[qa] - R(qpos0[qa]));
           }
           mulquat(r, xquat, qloc);
+          DMC_UNROLL
           for (int k = 0; k < 4; k++) xquat[k] = r[k];
           rotvecquat(vec, jp, xquat);
+          DMC_UNROLL
           for (int k = 0; k < 3; k++) xpos[k] = anchor[k] - vec[k];
         }
       }
     }
     normalize4(xquat);
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) E.xpos[3*i + k] = xpos[k];
+    DMC_UNROLL
     for (int k = 0; k < 4; k++) E.xquat[4*i + k] = xquat[k];
     quat2mat(E.xmat + 9*i, xquat);
     // inertial frame
@@ -342,6 +357,7 @@ DEV void kinematics(Env& E) {
                   R(body_iquat[4*i + 2]), R(body_iquat[4*i + 3])};
     real v[3], q[4];
     mulmatvec3(v, E.xmat + 9*i, ip);
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) E.xipos[3*i + k] = xpos[k] + v[k];
     mulquat(q, xquat, iq);
     quat2mat(E.ximat + 9*i, q);
@@ -351,21 +367,26 @@ DEV void kinematics(Env& E) {
 DEV void com_pos(Env& E) {
   DMC_UNROLL
   for (int i = 0; i < NBODY; i++)
+    DMC_UNROLL
     for (int k = 0; k < 3; k++)
       E.subtree_com[3*i + k] = R(body_mass[i])*E.xipos[3*i + k];
   DMC_UNROLL
   for (int i = NBODY - 1; i > 0; i--)
+    DMC_UNROLL
     for (int k = 0; k < 3; k++)
       E.subtree_com[3*body_parentid[i] + k] += E.subtree_com[3*i + k];
   DMC_UNROLL
   for (int i = 0; i < NBODY; i++) {
     if (body_subtreemass[i] < 1e-15) {
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] = E.xipos[3*i + k];
     } else {
       real inv = R(1.0/(body_subtreemass[i] < 1e-15 ? 1.0 : body_subtreemass[i]));
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] *= inv;
     }
   }
+  DMC_UNROLL
   for (int k = 0; k < 10; k++) E.cinert[k] = 0;
   DMC_UNROLL
   for (int i = 1; i < NBODY; i++) {
@@ -375,8 +396,11 @@ DEV void com_pos(Env& E) {
     const real mass = R(body_mass[i]);
     const real in0 = R(body_inertia[3*i]), in1 = R(body_inertia[3*i + 1]),
                in2 = R(body_inertia[3*i + 2]);
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) dif[k] = E.xipos[3*i + k] - com[k];
+    DMC_UNROLL
     for (int a = 0; a < 3; a++)
+      DMC_UNROLL
       for (int b = 0; b < 3; b++)
         t[3*a + b] = mat[3*a]*in0*mat[3*b] + mat[3*a + 1]*in1*mat[3*b + 1] +
                      mat[3*a + 2]*in2*mat[3*b + 2];
@@ -395,23 +419,29 @@ DEV void com_pos(Env& E) {
     const int b = jnt_bodyid[j], da = jnt_dofadr[j];
     const real* com = E.subtree_com + 3*body_rootid[b];
     real off[3];
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) off[k] = com[k] - E.xanchor[3*j + k];
     real* cd = E.cdof + 6*da;
     if (jnt_type[j] == JNT_FREE || jnt_type[j] == JNT_BALL) {
       if (jnt_type[j] == JNT_FREE) {
+        DMC_UNROLL
         for (int k = 0; k < 18; k++) cd[k] = 0;
         cd[3] = 1; cd[6 + 4] = 1; cd[12 + 5] = 1;
         cd += 18;
       }
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) {
         real ax[3] = {E.xmat[9*b + k], E.xmat[9*b + 3 + k], E.xmat[9*b + 6 + k]};
+        DMC_UNROLL
         for (int c = 0; c < 3; c++) cd[6*k + c] = ax[c];
         cross3(cd + 6*k + 3, ax, off);
       }
     } else if (jnt_type[j] == JNT_SLIDE) {
       cd[0] = cd[1] = cd[2] = 0;
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) cd[3 + k] = E.xaxis[3*j + k];
     } else {
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) cd[k] = E.xaxis[3*j + k];
       cross3(cd + 3, E.xaxis + 3*j, off);
     }
@@ -426,6 +456,7 @@ DEV void crb_factor(Env& E) {
   DMC_UNROLL
   for (int i = NBODY - 1; i > 0; i--)
     if (body_parentid[i] > 0)
+      DMC_UNROLL
       for (int k = 0; k < 10; k++) crb[10*body_parentid[i] + k] += crb[10*i + k];
   DMC_UNROLL
   for (int i = 0; i < NM; i++) E.qM[i] = 0;
@@ -450,33 +481,44 @@ DEV void crb_factor(Env& E) {
 // velocity stage: body velocities, passive forces, RNE bias
 // ---------------------------------------------------------------------------
 DEV void com_vel(Env& E) {
+  DMC_UNROLL
   for (int k = 0; k < 6; k++) E.cvel[k] = 0;
   DMC_UNROLL
   for (int i = 1; i < NBODY; i++) {
     real cvel[6];
+    DMC_UNROLL
     for (int k = 0; k < 6; k++) cvel[k] = E.cvel[6*body_parentid[i] + k];
     const int jadr = body_jntadr[i];
+    DMC_UNROLL
     for (int j = 0; j < body_jntnum[i]; j++) {
       const int jid = jadr + j;
       int da = jnt_dofadr[jid];
       if (jnt_type[jid] == JNT_FREE || jnt_type[jid] == JNT_BALL) {
         if (jnt_type[jid] == JNT_FREE) {
+          DMC_UNROLL
           for (int k = 0; k < 18; k++) E.cdof_dot[6*da + k] = 0;
+          DMC_UNROLL
           for (int k = 0; k < 3; k++)
+            DMC_UNROLL
             for (int c = 0; c < 6; c++)
               cvel[c] += E.cdof[6*(da + k) + c]*E.qvel[da + k];
           da += 3;
         }
+        DMC_UNROLL
         for (int k = 0; k < 3; k++)
           cross_motion(E.cdof_dot + 6*(da + k), cvel, E.cdof + 6*(da + k));
+        DMC_UNROLL
         for (int k = 0; k < 3; k++)
+          DMC_UNROLL
           for (int c = 0; c < 6; c++)
             cvel[c] += E.cdof[6*(da + k) + c]*E.qvel[da + k];
       } else {
         cross_motion(E.cdof_dot + 6*da, cvel, E.cdof + 6*da);
+        DMC_UNROLL
         for (int c = 0; c < 6; c++) cvel[c] += E.cdof[6*da + c]*E.qvel[da];
       }
     }
+    DMC_UNROLL
     for (int k = 0; k < 6; k++) E.cvel[6*i + k] = cvel[k];
   }
 }
@@ -484,25 +526,32 @@ DEV void com_vel(Env& E) {
 // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
 DEV void smooth_forces(Env& E, bool actuation) {
   real cacc[NBODY*6], cfrc[NBODY*6];
+  DMC_UNROLL
   for (int k = 0; k < 6; k++) { cacc[k] = 0; cfrc[k] = 0; }
   if (!(DISABLEFLAGS & DSBL_GRAVITY))
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) cacc[3 + k] = -R(gravity[k]);
   DMC_UNROLL
   for (int i = 1; i < NBODY; i++) {
     real tmp[6], tmp1[6];
     const int da = body_dofadr[i];
+    DMC_UNROLL
     for (int k = 0; k < 6; k++) cacc[6*i + k] = cacc[6*body_parentid[i] + k];
+    DMC_UNROLL
     for (int j = 0; j < body_dofnum[i]; j++)
+      DMC_UNROLL
       for (int k = 0; k < 6; k++)
         cacc[6*i + k] += E.cdof_dot[6*(da + j) + k]*E.qvel[da + j];
     mul_inert_vec(cfrc + 6*i, E.cinert + 10*i, cacc + 6*i);
     mul_inert_vec(tmp, E.cinert + 10*i, E.cvel + 6*i);
     cross_force(tmp1, E.cvel + 6*i, tmp);
+    DMC_UNROLL
     for (int k = 0; k < 6; k++) cfrc[6*i + k] += tmp1[k];
   }
   DMC_UNROLL
   for (int i = NBODY - 1; i > 0; i--)
     if (body_parentid[i] > 0)
+      DMC_UNROLL
       for (int k = 0; k < 6; k++) cfrc[6*body_parentid[i] + k] += cfrc[6*i + k];
   DMC_UNROLL
   for (int i = 0; i < NV; i++)
@@ -548,18 +597,22 @@ DEV void subtree_vel(Env& E) {
   for (int i = 0; i < NBODY; i++) {
     real dif[3], t[3];
     const real* com = E.subtree_com + 3*body_rootid[i];
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) dif[k] = E.xipos[3*i + k] - com[k];
     cross3(t, E.cvel + 6*i, dif);
+    DMC_UNROLL
     for (int k = 0; k < 3; k++)
       E.subtree_linvel[3*i + k] = R(body_mass[i])*(E.cvel[6*i + 3 + k] + t[k]);
   }
   DMC_UNROLL
   for (int i = NBODY - 1; i > 0; i--)
+    DMC_UNROLL
     for (int k = 0; k < 3; k++)
       E.subtree_linvel[3*body_parentid[i] + k] += E.subtree_linvel[3*i + k];
   DMC_UNROLL
   for (int i = 0; i < NBODY; i++) {
     real inv = R(1.0/(body_subtreemass[i] < 1e-15 ? 1e-15 : body_subtreemass[i]));
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) E.subtree_linvel[3*i + k] *= inv;
   }
 }
@@ -589,6 +642,7 @@ DEV void add_jac_dir(real* row, const Env& E, int body, const real* point,
   if (body_chain_len[body] == 0) return;
   real off[3], w[3];
   const int root = body_rootid[body];
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) off[k] = point[k] - E.subtree_com[3*root + k];
   cross3(w, off, dir);   // dir.(ang x off) = ang.(off x dir)
   DMC_UNROLL
@@ -635,6 +689,7 @@ DEV void limit_rows(Env& E, const Work& W) {
     const int j = limit_jnt[l], qa = jnt_qposadr[j], dof = jnt_dofadr[j];
     const real margin = R(jnt_margin[j]);
     const real q = E.qpos[qa];
+    DMC_UNROLL
     for (int side = -1; side <= 1; side += 2) {
       const real dist = side < 0 ? q - R(jnt_range[2*j]) : R(jnt_range[2*j + 1]) - q;
       if (dist < margin) {
@@ -654,6 +709,7 @@ DEV void limit_rows(Env& E, const Work& W) {
 struct RawCon { real dist, pos[3], frame[6]; };   // frame: normal, tangent hint
 
 DEV void make_frame(const real* fin, real* f) {   // f[9]
+  DMC_UNROLL
   for (int k = 0; k < 6; k++) f[k] = fin[k];
   normalize3(f);
   if (sqrt(dot3(f + 3, f + 3)) < R(0.5)) {
@@ -661,6 +717,7 @@ DEV void make_frame(const real* fin, real* f) {   // f[9]
     if (f[1] < R(0.5) && f[1] > R(-0.5)) f[4] = 1; else f[5] = 1;
   }
   real t = dot3(f, f + 3);
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) f[3 + k] -= t*f[k];
   normalize3(f + 3);
   cross3(f + 6, f, f + 3);
@@ -669,10 +726,12 @@ DEV void make_frame(const real* fin, real* f) {   // f[9]
 DEV int plane_sphere(RawCon* c, real margin, const real* ppos, const real* pn,
                      const real* spos, real r) {
   real dif[3];
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) dif[k] = spos[k] - ppos[k];
   const real dist = dot3(dif, pn) - r;
   if (dist > margin) return 0;
   c->dist = dist;
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) {
     c->pos[k] = spos[k] - pn[k]*(r + R(0.5)*dist);
     c->frame[k] = pn[k]; c->frame[3 + k] = 0;
@@ -682,6 +741,7 @@ DEV int plane_sphere(RawCon* c, real margin, const real* ppos, const real* pn,
 DEV int sphere_sphere(RawCon* c, real margin, const real* p1, const real* p2,
                       real r1, real r2) {
   real dif[3];
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) dif[k] = p2[k] - p1[k];
   const real len = sqrt(dot3(dif, dif));
   const real dist = len - r1 - r2;
@@ -689,6 +749,7 @@ DEV int sphere_sphere(RawCon* c, real margin, const real* p1, const real* p2,
   c->dist = dist;
   if (len < DMC_MINVAL) { c->frame[0] = 1; c->frame[1] = c->frame[2] = 0; }
   else for (int k = 0; k < 3; k++) c->frame[k] = dif[k]/len;
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) {
     c->pos[k] = p1[k] + c->frame[k]*(r1 + R(0.5)*dist);
     c->frame[3 + k] = 0;
@@ -704,12 +765,22 @@ DEV void geom_pose(const Env& E, int g, real* pos, real* mat) {
                 R(geom_quat[4*g + 3])};
   real v[3], q[4];
   mulmatvec3(v, E.xmat + 9*b, gp);
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) pos[k] = E.xpos[3*b + k] + v[k];
   mulquat(q, E.xquat + 4*b, gq);
   normalize4(q);
   quat2mat(mat, q);
 }
 
+// static-slot store: rc[cnt] = c without a dynamic index (cnt <= 3)
+DEV void put_slot(RawCon* rc, int cnt, const RawCon& c) {
+  if (cnt == 0) rc[0] = c;
+  else if (cnt == 1) rc[1] = c;
+  else if (cnt == 2) rc[2] = c;
+  else rc[3] = c;
+}
+
+// narrowphase of static pair p; returns a bit mask of valid contact slots
 DEV int collide_pair(const Env& E, int p, RawCon* rc) {
   const int g1 = pair_g1[p], g2 = pair_g2[p];
   const int t1 = geom_type[g1], t2 = geom_type[g2];
@@ -720,6 +791,7 @@ DEV int collide_pair(const Env& E, int p, RawCon* rc) {
   const real s1[3] = {R(geom_size[3*g1]), R(geom_size[3*g1 + 1]), R(geom_size[3*g1 + 2])};
   const real s2[3] = {R(geom_size[3*g2]), R(geom_size[3*g2 + 1]), R(geom_size[3*g2 + 2])};
   real dif[3];
+  DMC_UNROLL
   for (int k = 0; k < 3; k++) dif[k] = p2[k] - p1[k];
   if (t1 == GEOM_PLANE) {
     const real n[3] = {m1[2], m1[5], m1[8]};
@@ -728,19 +800,20 @@ DEV int collide_pair(const Env& E, int p, RawCon* rc) {
     if (t2 == GEOM_CAPSULE) {
       const real ax[3] = {m2[2], m2[5], m2[8]};
       real q[3];
-      int cnt = 0;
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) q[k] = p2[k] + ax[k]*s2[1];
-      int c1 = plane_sphere(rc, margin, p1, n, q, s2[0]);
-      if (c1) for (int k = 0; k < 3; k++) rc[0].frame[3 + k] = ax[k];
-      cnt += c1;
+      const int c1 = plane_sphere(rc, margin, p1, n, q, s2[0]);
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) q[k] = p2[k] - ax[k]*s2[1];
-      c1 = plane_sphere(rc + cnt, margin, p1, n, q, s2[0]);
-      if (c1) for (int k = 0; k < 3; k++) rc[cnt].frame[3 + k] = ax[k];
-      return cnt + c1;
+      const int c2 = plane_sphere(rc + 1, margin, p1, n, q, s2[0]);
+      DMC_UNROLL
+      for (int k = 0; k < 3; k++) { rc[0].frame[3 + k] = ax[k]; rc[1].frame[3 + k] = ax[k]; }
+      return c1 | (c2 << 1);
     }
     if (t2 == GEOM_BOX) {
       const real dist = dot3(dif, n);
       int cnt = 0;
+      DMC_UNROLL
       for (int i = 0; i < 8; i++) {
         real v[3] = {(i & 1) ? s2[0] : -s2[0], (i & 2) ? s2[1] : -s2[1],
                      (i & 4) ? s2[2] : -s2[2]};
@@ -748,14 +821,17 @@ DEV int collide_pair(const Env& E, int p, RawCon* rc) {
         mulmatvec3(corner, m2, v);
         const real ld = dot3(n, corner);
         if (dist + ld > margin || ld > 0 || cnt >= 4) continue;
-        rc[cnt].dist = dist + ld;
+        RawCon c;
+        c.dist = dist + ld;
+        DMC_UNROLL
         for (int k = 0; k < 3; k++) {
-          rc[cnt].pos[k] = corner[k] + p2[k] - n[k]*R(0.5)*(dist + ld);
-          rc[cnt].frame[k] = n[k]; rc[cnt].frame[3 + k] = 0;
+          c.pos[k] = corner[k] + p2[k] - n[k]*R(0.5)*(dist + ld);
+          c.frame[k] = n[k]; c.frame[3 + k] = 0;
         }
+        put_slot(rc, cnt, c);
         cnt++;
       }
-      return cnt;
+      return (1 << cnt) - 1;
     }
     return 0;
   }
@@ -768,13 +844,16 @@ DEV int collide_pair(const Env& E, int p, RawCon* rc) {
   if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) {
     const real ax[3] = {m2[2], m2[5], m2[8]};
     real v[3], q[3];
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) v[k] = p1[k] - p2[k];
     const real x = clampr(dot3(ax, v), -s2[1], s2[1]);
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) q[k] = p2[k] + ax[k]*x;
     return sphere_sphere(rc, margin, p1, q, s1[0], s2[0]);
   }
   if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) {
     real a1[3], a2[3], d[3], v1[3], v2[3];
+    DMC_UNROLL
     for (int k = 0; k < 3; k++) {
       a1[k] = m1[3*k + 2]*s1[1]; a2[k] = m2[3*k + 2]*s2[1]; d[k] = p1[k] - p2[k];
     }
@@ -787,30 +866,29 @@ DEV int collide_pair(const Env& E, int p, RawCon* rc) {
       else if (x1 < -1) { x1 = -1; x2 = (v + mb)/mc; }
       if (x2 > 1) { x2 = 1; x1 = clampr((u - mb)/ma, -1, 1); }
       else if (x2 < -1) { x2 = -1; x1 = clampr((u + mb)/ma, -1, 1); }
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) { v1[k] = p1[k] + a1[k]*x1; v2[k] = p2[k] + a2[k]*x2; }
       return sphere_sphere(rc, margin, v1, v2, s1[0], s2[0]);
     }
-    int n = 0;
-    real x;
-    for (int k = 0; k < 3; k++) v1[k] = p1[k] + a1[k];
-    x = clampr((v - mb)/mc, -1, 1);
-    for (int k = 0; k < 3; k++) v2[k] = p2[k] + a2[k]*x;
-    n += sphere_sphere(rc + n, margin, v1, v2, s1[0], s2[0]);
-    for (int k = 0; k < 3; k++) v1[k] = p1[k] - a1[k];
-    x = clampr((v + mb)/mc, -1, 1);
-    for (int k = 0; k < 3; k++) v2[k] = p2[k] + a2[k]*x;
-    n += sphere_sphere(rc + n, margin, v1, v2, s1[0], s2[0]);
-    if (n == 2) return n;
-    for (int k = 0; k < 3; k++) v2[k] = p2[k] + a2[k];
-    x = clampr((u - mb)/ma, -1, 1);
-    for (int k = 0; k < 3; k++) v1[k] = p1[k] + a1[k]*x;
-    n += sphere_sphere(rc + n, margin, v1, v2, s1[0], s2[0]);
-    if (n == 2) return n;
-    for (int k = 0; k < 3; k++) v2[k] = p2[k] - a2[k];
-    x = clampr((u + mb)/ma, -1, 1);
-    for (int k = 0; k < 3; k++) v1[k] = p1[k] + a1[k]*x;
-    n += sphere_sphere(rc + n, margin, v1, v2, s1[0], s2[0]);
-    return n;
+    // parallel axes: both ends of each segment, at most two contacts
+    int cnt = 0;
+    DMC_UNROLL
+    for (int t = 0; t < 4; t++) {
+      if (cnt >= 2) continue;
+      const real sgn = (t & 1) ? R(-1) : R(1);
+      if (t < 2) {
+        const real x = clampr((v - sgn*mb)/mc, -1, 1);
+        DMC_UNROLL
+        for (int k = 0; k < 3; k++) { v1[k] = p1[k] + sgn*a1[k]; v2[k] = p2[k] + a2[k]*x; }
+      } else {
+        const real x = clampr((u - sgn*mb)/ma, -1, 1);
+        DMC_UNROLL
+        for (int k = 0; k < 3; k++) { v2[k] = p2[k] + sgn*a2[k]; v1[k] = p1[k] + a1[k]*x; }
+      }
+      RawCon c;
+      if (sphere_sphere(&c, margin, v1, v2, s1[0], s2[0])) { put_slot(rc, cnt, c); cnt++; }
+    }
+    return (1 << cnt) - 1;
   }
   return 0;
 }
@@ -820,8 +898,15 @@ DEVN void contact_rows(Env& E, const Work& W) {
   DMC_UNROLL
   for (int p = 0; p < NPAIR; p++) {
     RawCon rc[4];
-    const int n = collide_pair(E, p, rc);
-    for (int c = 0; c < n; c++) {
+    const int mask = collide_pair(E, p, rc);
+    if (mask == 0) continue;
+    // at most 2 contacts per pair except plane-box (4); with p folded to a
+    // constant by the unroller the slot index below is static
+    const int t1s = geom_type[pair_g1[p]], t2s = geom_type[pair_g2[p]];
+    const int maxc = t1s == GEOM_PLANE ? (t2s == GEOM_BOX ? 4 : t2s == GEOM_CAPSULE ? 2 : 1) : 2;
+    DMC_UNROLL
+    for (int c = 0; c < 4; c++) {
+      if (c >= maxc || !((mask >> c) & 1)) continue;
       if (E.ncon >= NCON_MAX) { E.warn |= WARN_CONTACTFULL; return; }
       E.ncon++;
       const real includemargin = R(pair_includemargin[p]);
@@ -848,7 +933,9 @@ DEVN void contact_rows(Env& E, const Work& W) {
       real R0 = (1 - imp)*R(pair_diag[6*p + 1])/imp;
       if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
       const real Rpy = 2*mu0*mu0*R0;
-      for (int k = 1; k < dim; k++) {
+      DMC_UNROLL
+      for (int k = 1; k < 6; k++) {
+        if (k >= dim) continue;
         real jt[NVX], row[NVX];
         DMC_UNROLL
         for (int j = 0; j < NV; j++) jt[j] = 0;
@@ -1002,10 +1089,16 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
   smooth_forces(E, actuation);
   E.ncon = 0; E.nefc = 0; E.iters = 0;
   limit_rows(E, W);
+#ifndef DMC_ABLATE_CONTACT
   if (NPAIR > 0) contact_rows(E, W);
+#endif
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
+#ifdef DMC_ABLATE_SOLVER
+  if (true) {
+#else
   if (E.nefc == 0) {
+#endif
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qacc[i] = E.qacc_smooth[i];
   } else {
@@ -1052,6 +1145,7 @@ DEV void integrate_pos(real* qpos, const real* qvel, real h) {
   for (int j = 0; j < NJNT; j++) {
     const int qa = jnt_qposadr[j], da = jnt_dofadr[j];
     if (jnt_type[j] == JNT_FREE) {
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) qpos[qa + k] += h*qvel[da + k];
       quat_integrate(qpos + qa + 3, qvel + da + 3, h);
     } else if (jnt_type[j] == JNT_BALL) {
@@ -1131,6 +1225,7 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) { Fv[i] = E.qvel[i]; Fa[i] = E.qacc[i]; }
     const real Acoef[3] = {R(0.5), R(0.5), R(1)};
+    DMC_UNROLL
     for (int s = 1; s < 4; s++) {
       const real a = Acoef[s - 1];
       DMC_UNROLL
@@ -1201,12 +1296,14 @@ DEV real task_outputs(const Env& E, const DmcArgs& a, int e) {
     const int npole = NBODY - 2;
     OBS(0) = E.qpos[0];
     real upright = 0, sparse_angle = 1, minvel = 1;
+    DMC_UNROLL
     for (int p = 0; p < npole; p++) {
       const real czz = E.xmat[9*(2 + p) + 8], sxz = E.xmat[9*(2 + p) + 2];
       OBS(1 + 2*p) = czz; OBS(2 + 2*p) = sxz;
       upright += (czz + 1)*R(0.5);
       sparse_angle *= tolerance(czz, R(0.995), R(1), 0, SIG_GAUSSIAN, R(0.1));
     }
+    DMC_UNROLL
     for (int i = 0; i < NV; i++) OBS(1 + 2*npole + i) = E.qvel[i];
     if (a.task_param_i & 1) {   // sparse
       reward = tolerance(E.qpos[0], R(-0.25), R(0.25), 0, SIG_GAUSSIAN, R(0.1))*sparse_angle;
@@ -1216,6 +1313,7 @@ DEV real task_outputs(const Env& E, const DmcArgs& a, int e) {
       centered = (1 + centered)*R(0.5);
       real small_control = tolerance(E.ctrl[0], 0, 0, 1, SIG_QUADRATIC, 0);
       small_control = (4 + small_control)/5;
+      DMC_UNROLL
       for (int i = 1; i < NV; i++) {
         const real t = tolerance(E.qvel[i], 0, 0, 5, SIG_GAUSSIAN, R(0.1));
         minvel = t < minvel ? t : minvel;
@@ -1225,7 +1323,9 @@ DEV real task_outputs(const Env& E, const DmcArgs& a, int e) {
     }
   } else if (TASK == TASK_CHEETAH) {
     // cheetah.py:79-93
+    DMC_UNROLL
     for (int i = 1; i < NQ; i++) OBS(i - 1) = E.qpos[i];
+    DMC_UNROLL
     for (int i = 0; i < NV; i++) OBS(NQ - 1 + i) = E.qvel[i];
     const real speed = E.subtree_linvel[3*task_body[0]];
     reward = tolerance(speed, 10, inf, 10, SIG_LINEAR, 0);
@@ -1233,24 +1333,32 @@ DEV real task_outputs(const Env& E, const DmcArgs& a, int e) {
     // humanoid.py:96-129,168-207; task_body = torso, head, l_hand, l_foot, r_hand, r_foot
     const int torso = task_body[0], head = task_body[1];
     int o = 0;
+    DMC_UNROLL
     for (int i = 7; i < NQ; i++) OBS(o++) = E.qpos[i];
     const real head_height = E.xpos[3*head + 2];
     OBS(o++) = head_height;
+    DMC_UNROLL
     for (int l = 0; l < 4; l++) {
       const int b = task_body[2 + l];
       real d[3];
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) d[k] = E.xpos[3*b + k] - E.xpos[3*torso + k];
+      DMC_UNROLL
       for (int c = 0; c < 3; c++)
         OBS(o++) = d[0]*E.xmat[9*torso + c] + d[1]*E.xmat[9*torso + 3 + c] +
                    d[2]*E.xmat[9*torso + 6 + c];
     }
+    DMC_UNROLL
     for (int c = 0; c < 3; c++) OBS(o++) = E.xmat[9*torso + 6 + c];
     const real* cv = E.subtree_linvel + 3*torso;
+    DMC_UNROLL
     for (int c = 0; c < 3; c++) OBS(o++) = cv[c];
+    DMC_UNROLL
     for (int i = 0; i < NV; i++) OBS(o++) = E.qvel[i];
     const real standing = tolerance(head_height, R(1.4), inf, R(0.35), SIG_GAUSSIAN, R(0.1));
     const real upright = tolerance(E.xmat[9*torso + 8], R(0.9), inf, R(1.9), SIG_LINEAR, 0);
     real sc = 0;
+    DMC_UNROLL
     for (int i = 0; i < NU; i++) sc += tolerance(E.ctrl[i], 0, 0, 1, SIG_QUADRATIC, 0);
     const real small_control = (4 + sc/NU)/5;
     const real move_speed = R(a.task_param_r[0]);
@@ -1265,7 +1373,9 @@ DEV real task_outputs(const Env& E, const DmcArgs& a, int e) {
       reward = small_control*standing*upright*move;
     }
   } else {
+    DMC_UNROLL
     for (int i = 0; i < NQ; i++) OBS(i) = E.qpos[i];
+    DMC_UNROLL
     for (int i = 0; i < NV; i++) OBS(NQ + i) = E.qvel[i];
   }
   return reward;
@@ -1297,19 +1407,28 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate) {
   const real rew = task_outputs(E, a, e);
   a.reward[e] = rew;
   if (accumulate) a.episode_return[e] += rew;
+  DMC_UNROLL
   for (int s = 0; s < NSENSOR; s++) {
     const int adr = sensor_adr[s], o = sensor_objid[s];
     if (sensor_type[s] == 35)
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) a.sensordata[(adr + k)*n + e] = E.subtree_linvel[3*o + k];
     else if (sensor_type[s] == 34)
+      DMC_UNROLL
       for (int k = 0; k < 3; k++) a.sensordata[(adr + k)*n + e] = E.subtree_com[3*o + k];
     else if (sensor_type[s] == 8)
       a.sensordata[adr*n + e] = E.qpos[jnt_qposadr[o]];
     else if (sensor_type[s] == 9)
       a.sensordata[adr*n + e] = E.qvel[jnt_dofadr[o]];
   }
-  if (a.xpos) for (int i = 0; i < NBODY*3; i++) a.xpos[i*n + e] = E.xpos[i];
-  if (a.xmat) for (int i = 0; i < NBODY*9; i++) a.xmat[i*n + e] = E.xmat[i];
+  if (a.xpos) {
+    DMC_UNROLL
+    for (int i = 0; i < NBODY*3; i++) a.xpos[i*n + e] = E.xpos[i];
+  }
+  if (a.xmat) {
+    DMC_UNROLL
+    for (int i = 0; i < NBODY*9; i++) a.xmat[i*n + e] = E.xmat[i];
+  }
   a.stats[e] = E.ncon; a.stats[n + e] = E.nefc; a.stats[2*n + e] = E.iters;
 }
 
@@ -1325,25 +1444,34 @@ dmc_step(DmcArgs a) {
   const long long n = a.nenv;
   if (a.flags & 1) {
     bool bc = false;
+    DMC_UNROLL
     for (int i = 0; i < NU; i++) {
       E.ctrl[i] = a.ctrl[i*a.ctrl_sk + (long long)e*a.ctrl_se];
       bc |= bad(E.ctrl[i]);
     }
     if (bc) {   // mj_fwdActuation's ctrl check: warn and zero the controls
       E.warn |= WARN_BADCTRL;
+      DMC_UNROLL
       for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
     }
+    DMC_UNROLL
     for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
   } else {
+    DMC_UNROLL
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
   __shared__ real lds_rows[(LDS_ROWS > 0 ? LDS_ROWS : 1)*RW*64];
   Work W = {lds_rows + threadIdx.x, a.ws + e, n};
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
   for (int s = 0; s < a.nsub; s++) physics_step(E, W, time, tol);
-  if (a.qacc) for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];
+  if (a.qacc) {
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];
+  }
   if (!(a.flags & 2)) {
+#ifndef DMC_ABLATE_OBS
     observe_stage(E, time);
+#endif
     store_outputs(E, a, e, true);
   }
   store_env(E, a, e, time);
@@ -1358,6 +1486,7 @@ dmc_observe(DmcArgs a) {
   real time;
   load_env(E, a, e, time);
   const long long n = a.nenv;
+  DMC_UNROLL
   for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   observe_stage(E, time);
   if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
@@ -1400,7 +1529,9 @@ dmc_init_episode(DmcArgs a) {
   if ((a.flags & 8) && a.stats[e] == 0) return;
   Rng rng = {a.seed*0x2545F4914F6CDD1DULL + (uint64_t)e, 0};
   real qpos[NQ > 0 ? NQ : 1], qvel[NVX];
+  DMC_UNROLL
   for (int i = 0; i < NQ; i++) qpos[i] = R(qpos0[i]);
+  DMC_UNROLL
   for (int i = 0; i < NV; i++) qvel[i] = 0;
   if (a.flags & DMC_FLAG_RESET_ONLY) {
     // mj_resetData only
@@ -1408,13 +1539,17 @@ dmc_init_episode(DmcArgs a) {
     if (a.task_param_i & 2) {   // swing_up
       qpos[0] = R(0.01)*rng.normal();
       qpos[1] = R(3.141592653589793) + R(0.01)*rng.normal();
+      DMC_UNROLL
       for (int i = 2; i < NQ; i++) qpos[i] = R(0.1)*rng.normal();
     } else {
       qpos[0] = R(-0.1) + R(0.2)*rng.uniform();
+      DMC_UNROLL
       for (int i = 1; i < NQ; i++) qpos[i] = R(-0.034) + R(0.068)*rng.uniform();
     }
+    DMC_UNROLL
     for (int i = 0; i < NV; i++) qvel[i] = R(0.01)*rng.normal();
   } else if (TASK == TASK_CHEETAH || TASK == TASK_HUMANOID) {
+    DMC_UNROLL
     for (int j = 0; j < NJNT; j++) {
       const int qa = jnt_qposadr[j];
       if (jnt_limited[j] && (jnt_type[j] == JNT_HINGE || jnt_type[j] == JNT_SLIDE)) {
@@ -1425,15 +1560,20 @@ dmc_init_episode(DmcArgs a) {
           qpos[qa] = R(-3.141592653589793) + R(6.283185307179586)*rng.uniform();
         } else if (jnt_type[j] == JNT_FREE) {
           real q[4];
+          DMC_UNROLL
           for (int k = 0; k < 4; k++) q[k] = rng.uniform();
           normalize4(q);
+          DMC_UNROLL
           for (int k = 0; k < 4; k++) qpos[qa + 3 + k] = q[k];
         }
       }
     }
   }
+  DMC_UNROLL
   for (int i = 0; i < NQ; i++) a.qpos[i*n + e] = qpos[i];
+  DMC_UNROLL
   for (int i = 0; i < NV; i++) { a.qvel[i*n + e] = qvel[i]; a.warm[i*n + e] = 0; }
+  DMC_UNROLL
   for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = 0;
   a.time[e] = 0;
   a.episode_return[e] = 0;
