@@ -45,12 +45,24 @@ def build_library(force=False):
   return LIB_PATH
 
 
-def model_key(model, task, precision, ncon_max=None, extra_flags=()):
+# Spill budget of the fully unrolled ("static") build.  Kernels far beyond it
+# (fp64 builds of 20-dof models: ~1900 VGPR + ~200 SGPR spills, 300 KB of code)
+# have produced wrong results on gfx950 with ROCm 7.2 while the same source is
+# correct on the host under ASan/UBSan and with gcc/clang -O3 (see DESIGN.md,
+# "compiler hazard"), so `mode="auto"` falls back to the rolled build, whose
+# per-lane arrays are explicit scratch objects instead of register spills.
+MAX_VGPR_SPILLS = 128
+MAX_SGPR_SPILLS = 128
+
+
+def model_key(model, task, precision, ncon_max=None, extra_flags=(),
+              unroll=True):
   src = os.path.join(_CSRC, 'dmc_kernels.hip')
   h = hashlib.sha1()
   h.update(model.content_hash().encode())
-  h.update(('%d/%s/%r/%r' % (task, precision, ncon_max,
-                             tuple(extra_flags))).encode())
+  h.update(('%d/%s/%r/%r/%s/%d' % (
+      task, precision, ncon_max, tuple(extra_flags),
+      os.environ.get('DMC_PRAGMA_UNROLL_THRESHOLD', ''), int(unroll))).encode())
   for path in (src, os.path.join(_CSRC, 'dmc_args.h'),
                codegen.__file__):
     with open(path, 'rb') as f:
@@ -58,32 +70,26 @@ def model_key(model, task, precision, ncon_max=None, extra_flags=()):
   return h.hexdigest()[:20]
 
 
-def code_object_path(model, task=codegen.TASK_NONE, precision='f32',
-                     ncon_max=None, extra_flags=()):
-  return os.path.join(_BUILD, 'dmc_%s.hsaco' % model_key(
-      model, task, precision, ncon_max, extra_flags))
+def _spills(remarks, kernel='dmc_step'):
+  """(vgpr, sgpr) spill counts of `kernel` from -Rpass-analysis remarks."""
+  vg = sg = 0
+  inside = False
+  for line in remarks.splitlines():
+    if 'Function Name:' in line:
+      inside = ('Function Name: %s ' % kernel) in line + ' '
+    elif inside and 'VGPRs Spill:' in line:
+      vg = int(line.split('VGPRs Spill:')[1].split()[0])
+    elif inside and 'SGPRs Spill:' in line:
+      sg = int(line.split('SGPRs Spill:')[1].split()[0])
+  return vg, sg
 
 
-def build_model(model, task=codegen.TASK_NONE, precision='f32',
-                ncon_max=None, force=False, keep_temps=False, extra_flags=None):
-  """Generates the constants header for `model` and compiles its kernels.
-
-  Returns the path of the gfx950 code object.  Built lazily and cached by
-  content hash; `__graft_entry__.build()` pre-builds the suite models.
-  """
-  if precision not in ('f32', 'f64'):
-    raise ValueError('precision must be "f32" or "f64"')
-  os.makedirs(_BUILD, exist_ok=True)
-  if extra_flags is None:
-    # experiment hook: extra -D flags for ablation builds (never set in tests)
-    extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
-  out = code_object_path(model, task, precision, ncon_max, extra_flags)
-  if os.path.exists(out) and not force:
-    return out
+def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
+             keep_temps):
   key = os.path.basename(out)[4:-6]
   header = os.path.join(_BUILD, 'model_%s.h' % key)
   with open(header, 'w') as f:
-    f.write(codegen.generate_header(model, task, ncon_max))
+    f.write(codegen.generate_header(model, task, ncon_max, unroll=unroll))
   # -pragma-unroll-threshold: the per-model straight-line code is far beyond
   #   LLVM's default budget; without it the pair loop stays rolled, per-lane
   #   arrays are indexed dynamically and the whole working set lands in scratch.
@@ -93,7 +99,9 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
   #   based division and sqrt (<= 2.5 ulp) instead of the 10-instruction
   #   IEEE sequences; the fp64 build keeps exact division.
   cmd = [_hipcc(), '--genco', '--offload-arch=' + ARCH, '-O3', '-std=c++17',
-         '-mllvm', '-pragma-unroll-threshold=10000000', '-fno-slp-vectorize',
+         '-Rpass-analysis=kernel-resource-usage',
+         '-mllvm', '-pragma-unroll-threshold=%s' % os.environ.get(
+             'DMC_PRAGMA_UNROLL_THRESHOLD', '10000000'), '-fno-slp-vectorize',
          '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast',
          '-DDMC_MODEL_HEADER="%s"' % header, '-I', _CSRC,
          '-o', out + '.tmp', os.path.join(_CSRC, 'dmc_kernels.hip')]
@@ -103,10 +111,58 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
   else:
     cmd.insert(1, '-fno-hip-fp32-correctly-rounded-divide-sqrt')
   if keep_temps:
-    cmd[1:1] = ['-save-temps', '-Rpass-analysis=kernel-resource-usage']
-  try:
-    subprocess.check_call(cmd, cwd=_BUILD)
-  except subprocess.CalledProcessError as e:
-    raise RuntimeError('hipcc failed for model kernels: %s' % e)
+    cmd.insert(1, '-save-temps')
+  proc = subprocess.run(cmd, cwd=_BUILD, stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, universal_newlines=True)
+  if proc.returncode != 0:
+    raise RuntimeError('hipcc failed for model kernels:\n%s'
+                       % proc.stdout[-4000:])
+  if keep_temps:
+    print(proc.stdout)
+  return _spills(proc.stdout)
+
+
+def build_model(model, task=codegen.TASK_NONE, precision='f32',
+                ncon_max=None, force=False, keep_temps=False, extra_flags=None,
+                mode='auto'):
+  """Generates the constants header for `model` and compiles its kernels.
+
+  mode: "unrolled" (static indexing, per-lane state in registers), "rolled"
+  (generic loops, per-lane arrays in scratch) or "auto" (unrolled unless its
+  register spills exceed MAX_*_SPILLS).  Returns the path of the gfx950 code
+  object; cached in-tree by content hash.
+  """
+  if precision not in ('f32', 'f64'):
+    raise ValueError('precision must be "f32" or "f64"')
+  if mode not in ('auto', 'unrolled', 'rolled'):
+    raise ValueError('mode must be auto, unrolled or rolled')
+  if extra_flags is None:
+    # experiment hook: extra -D flags for ablation builds (never set in tests)
+    extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
+  os.makedirs(_BUILD, exist_ok=True)
+
+  def path(unroll):
+    return os.path.join(_BUILD, 'dmc_%s.hsaco' % model_key(
+        model, task, precision, ncon_max, extra_flags, unroll))
+  marker = path(True) + '.rolled'     # "auto" decided against the unrolled build
+  if not force:
+    if mode != 'rolled' and os.path.exists(path(True)):
+      return path(True)
+    if mode != 'unrolled' and os.path.exists(path(False)) and (
+        mode == 'rolled' or os.path.exists(marker)):
+      return path(False)
+  if mode != 'rolled':
+    out = path(True)
+    vg, sg = _compile(model, task, precision, ncon_max, extra_flags, True, out,
+                      keep_temps)
+    if mode == 'unrolled' or (vg <= MAX_VGPR_SPILLS and sg <= MAX_SGPR_SPILLS):
+      os.replace(out + '.tmp', out)
+      return out
+    os.remove(out + '.tmp')
+    with open(marker, 'w') as f:
+      f.write('vgpr spills %d, sgpr spills %d\n' % (vg, sg))
+  out = path(False)
+  _compile(model, task, precision, ncon_max, extra_flags, False, out,
+           keep_temps)
   os.replace(out + '.tmp', out)
   return out

@@ -183,7 +183,7 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   refsafe = not (m.opt.disableflags & mdl.DSBL_REFSAFE)
   dt = float(m.opt.timestep)
   if unroll is None:
-    unroll = m.nv <= 12 and m.nbody <= 10
+    unroll = True
 
   limit_jnt = [j for j in range(m.njnt)
                if m.jnt_limited[j] and m.jnt_type[j] in (mdl.JNT_HINGE,
@@ -225,6 +225,11 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   w('typedef float dmc_real;')
   w('#endif')
   w('#define DMC_UNROLL %s' % ('_Pragma("unroll")' if unroll else ''))
+  # the static pair list is unrolled only while it stays small; larger models
+  # keep a rolled narrowphase loop over a per-lane geom-pose mirror
+  w('#define DMC_UNROLL_PAIRS %s' % (
+      '_Pragma("unroll")' if unroll and len(pairs) <= 40 else ''))
+  w('#define DMC_PAIRS_UNROLLED %d' % (1 if unroll and len(pairs) <= 40 else 0))
   w('namespace dmc_model {')
 
   def ci(name, v):
@@ -300,6 +305,26 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
       d = int(m.dof_parentid[d])
     ancs.append(a)
   maxchain = max([1] + [len(c) for c in chains] + [len(a) for a in ancs])
+  # per-body dof masks (bit j set: dof j moves the body), root list
+  masks = []
+  for c in chains:
+    bits = 0
+    for d in c:
+      bits |= 1 << d
+    masks.append(bits)
+  if m.nv > 64:
+    raise UnsupportedModelError('nv > 64 is not supported')
+  roots = sorted(set(int(r) for r in m.body_rootid[1:])) or [0]
+  ci('NROOT', len(roots))
+  ti('root_body', roots)
+  ti('body_rootidx', [roots.index(int(r)) if int(r) in roots else 0
+                      for r in m.body_rootid])
+  w('static __device__ constexpr unsigned body_dofmask_lo[] = {%s};'
+    % ', '.join('%du' % (b & 0xffffffff) for b in masks))
+  w('static __device__ constexpr unsigned body_dofmask_hi[] = {%s};'
+    % ', '.join('%du' % (b >> 32) for b in masks))
+  ti('pair_b1', [int(m.geom_bodyid[p[0]]) for p in pairs])
+  ti('pair_b2', [int(m.geom_bodyid[p[1]]) for p in pairs])
   ci('MAXCHAIN', maxchain)
   ti('body_chain_len', [len(c) for c in chains])
   ti('body_chain', [v for c in chains for v in (c + [0]*maxchain)[:maxchain]])

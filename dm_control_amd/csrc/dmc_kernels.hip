@@ -20,7 +20,9 @@
 // `real` is float (default) or double (-DDMC_REAL_IS_DOUBLE) -- the fp64 build
 // is the tight-parity mode, the fp32 build is the throughput mode.
 
+#ifndef DMC_HOST_SHIM
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 #ifdef DMC_REAL_IS_DOUBLE
@@ -239,12 +241,21 @@ struct Env {
 // LDS_ROWS records of each lane live in LDS ([record word][lane]: every lane
 // hits its own bank, conflict-free for any per-lane row index); records beyond
 // that spill to the HBM workspace with the same [word][env] layout.
+// Contact records ([pos3 n3 tangent-hint3 dist pair]) use the same two tiers.
 constexpr int RW = NV + 4;
+constexpr int CW = 11;
 #ifndef DMC_LDS_BUDGET
 #define DMC_LDS_BUDGET (128*1024)
 #endif
-constexpr int LDS_ROWS_FIT = DMC_LDS_BUDGET/(RW*64*(int)sizeof(real));
+#ifndef DMC_CON_LDS
+#define DMC_CON_LDS 12
+#endif
+constexpr int LDS_CONS = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
+constexpr int LDS_ROWS_FIT =
+    (DMC_LDS_BUDGET - LDS_CONS*CW*64*(int)sizeof(real))/(RW*64*(int)sizeof(real));
 constexpr int LDS_ROWS = LDS_ROWS_FIT < NEFC_MAX ? LDS_ROWS_FIT : NEFC_MAX;
+constexpr int GLB_ROWS = NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 0;
+constexpr int GLB_CONS = NCON_MAX - LDS_CONS > 0 ? NCON_MAX - LDS_CONS : 0;
 enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3 };
 
 struct LdsRow {
@@ -258,14 +269,21 @@ struct GlbRow {
   __device__ __forceinline__ void set(int k, real v) const { p[k*n] = v; }
 };
 struct Work {
-  real* lds;   // LDS base + lane
-  real* glb;   // workspace base + env
+  real* lds;   // LDS base + lane (rows first, then contact records)
+  real* glb;   // workspace base + env (overflow rows, then overflow contacts)
   long long nenv;
   __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*64}; }
   __device__ __forceinline__ GlbRow grow(int r) const {
     return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
   }
+  __device__ __forceinline__ LdsRow lcon(int k) const {
+    return LdsRow{lds + (LDS_ROWS*RW + k*CW)*64};
+  }
+  __device__ __forceinline__ GlbRow gcon(int k) const {
+    return GlbRow{glb + ((long long)GLB_ROWS*RW + (long long)(k - LDS_CONS)*CW)*nenv, nenv};
+  }
 };
+constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW > 0 ? LDS_ROWS*RW + LDS_CONS*CW : 1)*64;
 // f(row handle) for rows [0, nefc): LDS tier first, then the HBM tier
 template <class F>
 static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) {
@@ -757,19 +775,30 @@ DEV int sphere_sphere(RawCon* c, real margin, const real* p1, const real* p2,
   return 1;
 }
 
-// geom world pose on demand (body pose x local offset)
-DEV void geom_pose(const Env& E, int g, real* pos, real* mat) {
-  const int b = geom_bodyid[g];
-  real gp[3] = {R(geom_pos[3*g]), R(geom_pos[3*g + 1]), R(geom_pos[3*g + 2])};
-  real gq[4] = {R(geom_quat[4*g]), R(geom_quat[4*g + 1]), R(geom_quat[4*g + 2]),
-                R(geom_quat[4*g + 3])};
-  real v[3], q[4];
-  mulmatvec3(v, E.xmat + 9*b, gp);
+// world poses of all geoms, computed once per step: G[12*g] = pos(3), mat(9).
+// The narrowphase reads only this mirror, so a rolled pair loop (large models)
+// indexes G dynamically while Env itself stays statically indexed.
+DEV void geom_poses(const Env& E, real* G) {
   DMC_UNROLL
-  for (int k = 0; k < 3; k++) pos[k] = E.xpos[3*b + k] + v[k];
-  mulquat(q, E.xquat + 4*b, gq);
-  normalize4(q);
-  quat2mat(mat, q);
+  for (int g = 0; g < NGEOM; g++) {
+    const int b = geom_bodyid[g];
+    real gp[3] = {R(geom_pos[3*g]), R(geom_pos[3*g + 1]), R(geom_pos[3*g + 2])};
+    real gq[4] = {R(geom_quat[4*g]), R(geom_quat[4*g + 1]), R(geom_quat[4*g + 2]),
+                  R(geom_quat[4*g + 3])};
+    real v[3], q[4];
+    mulmatvec3(v, E.xmat + 9*b, gp);
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) G[12*g + k] = E.xpos[3*b + k] + v[k];
+    mulquat(q, E.xquat + 4*b, gq);
+    normalize4(q);
+    quat2mat(G + 12*g + 3, q);
+  }
+}
+DEV void geom_pose(const real* G, int g, real* pos, real* mat) {
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) pos[k] = G[12*g + k];
+  DMC_UNROLL
+  for (int k = 0; k < 9; k++) mat[k] = G[12*g + 3 + k];
 }
 
 // static-slot store: rc[cnt] = c without a dynamic index (cnt <= 3)
@@ -781,13 +810,13 @@ DEV void put_slot(RawCon* rc, int cnt, const RawCon& c) {
 }
 
 // narrowphase of static pair p; returns a bit mask of valid contact slots
-DEV int collide_pair(const Env& E, int p, RawCon* rc) {
+DEV int collide_pair(const real* G, int p, RawCon* rc) {
   const int g1 = pair_g1[p], g2 = pair_g2[p];
   const int t1 = geom_type[g1], t2 = geom_type[g2];
   const real margin = R(pair_margin[p]);
   real p1[3], m1[9], p2[3], m2[9];
-  geom_pose(E, g1, p1, m1);
-  geom_pose(E, g2, p2, m2);
+  geom_pose(G, g1, p1, m1);
+  geom_pose(G, g2, p2, m2);
   const real s1[3] = {R(geom_size[3*g1]), R(geom_size[3*g1 + 1]), R(geom_size[3*g1 + 2])};
   const real s2[3] = {R(geom_size[3*g2]), R(geom_size[3*g2 + 1]), R(geom_size[3*g2 + 2])};
   real dif[3];
@@ -893,69 +922,140 @@ DEV int collide_pair(const Env& E, int p, RawCon* rc) {
   return 0;
 }
 
-DEVN void contact_rows(Env& E, const Work& W) {
-  if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return;
+template <class Rec>
+DEV void write_contact(const Rec& rec, int p, const RawCon& c) {
   DMC_UNROLL
+  for (int k = 0; k < 3; k++) {
+    rec.set(k, c.pos[k]); rec.set(3 + k, c.frame[k]); rec.set(6 + k, c.frame[3 + k]);
+  }
+  rec.set(9, c.dist);
+  rec.set(10, (real)p);
+}
+
+// phase 1: narrowphase over the static pair list -> compact contact list
+DEV void detect_contacts(Env& E, const Work& W) {
+  if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return;
+  real G[NGEOM*12];
+  geom_poses(E, G);
+  DMC_UNROLL_PAIRS
   for (int p = 0; p < NPAIR; p++) {
     RawCon rc[4];
-    const int mask = collide_pair(E, p, rc);
+    const int mask = collide_pair(G, p, rc);
     if (mask == 0) continue;
-    // at most 2 contacts per pair except plane-box (4); with p folded to a
-    // constant by the unroller the slot index below is static
-    const int t1s = geom_type[pair_g1[p]], t2s = geom_type[pair_g2[p]];
-    const int maxc = t1s == GEOM_PLANE ? (t2s == GEOM_BOX ? 4 : t2s == GEOM_CAPSULE ? 2 : 1) : 2;
-    DMC_UNROLL
+    _Pragma("unroll")
     for (int c = 0; c < 4; c++) {
-      if (c >= maxc || !((mask >> c) & 1)) continue;
-      if (E.ncon >= NCON_MAX) { E.warn |= WARN_CONTACTFULL; return; }
-      E.ncon++;
-      const real includemargin = R(pair_includemargin[p]);
-      if (rc[c].dist >= includemargin) continue;
-      real f[9];
-      make_frame(rc[c].frame, f);
-      const int b1 = geom_bodyid[pair_g1[p]], b2 = geom_bodyid[pair_g2[p]];
-      const int dim = pair_dim[p];
-      const real pm = rc[c].dist - includemargin;
-      const real imp = impedance(pair_solimp + 5*p, pm);
-      const real K = R(pair_K[p]), B = R(pair_B[p]);
-      real jn[NVX];
-      DMC_UNROLL
-      for (int j = 0; j < NV; j++) jn[j] = 0;
-      add_jac_dir(jn, E, b2, rc[c].pos, f, R(1));
-      add_jac_dir(jn, E, b1, rc[c].pos, f, R(-1));
-      if (dim == 1) {
-        const real Rr = (1 - imp)*R(pair_diag[6*p])/imp;
-        if (!push_row(E, W, jn, pm, K, B, imp, Rr)) return;
-        continue;
-      }
-      // pyramidal: every edge gets 2 mu0^2 R(first edge)
-      const real mu0 = R(pair_friction[5*p]);
-      real R0 = (1 - imp)*R(pair_diag[6*p + 1])/imp;
-      if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
-      const real Rpy = 2*mu0*mu0*R0;
-      DMC_UNROLL
-      for (int k = 1; k < 6; k++) {
-        if (k >= dim) continue;
-        real jt[NVX], row[NVX];
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) jt[j] = 0;
-        if (k < 3) {
-          add_jac_dir(jt, E, b2, rc[c].pos, f + 3*k, R(1));
-          add_jac_dir(jt, E, b1, rc[c].pos, f + 3*k, R(-1));
-        } else {
-          add_jac_rot(jt, E, b2, f + 3*(k - 3), R(1));
-          add_jac_rot(jt, E, b1, f + 3*(k - 3), R(-1));
-        }
-        const real mu = R(pair_friction[5*p + k - 1]);
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) row[j] = jn[j] + mu*jt[j];
-        if (!push_row(E, W, row, pm, K, B, imp, Rpy)) return;
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) row[j] = jn[j] - mu*jt[j];
-        if (!push_row(E, W, row, pm, K, B, imp, Rpy)) return;
-      }
+      if (!((mask >> c) & 1)) continue;
+      if (E.ncon >= NCON_MAX) { E.warn |= WARN_CONTACTFULL; continue; }
+      const int k = E.ncon++;
+      if (LDS_CONS >= NCON_MAX || k < LDS_CONS) write_contact(W.lcon(k), p, rc[c]);
+      else write_contact(W.gcon(k), p, rc[c]);
     }
   }
+}
+
+// phase 2: one generic row builder, run once per contact of the busiest lane.
+// The pair index is per-lane data, so pair parameters come from the constant
+// tables through vector loads, and the body chains are applied as dof bit
+// masks over the statically indexed cdof registers (no dynamic indexing of
+// per-lane state).
+template <class Rec>
+DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
+  const int p = (int)rec.get(10);
+  const real dist = rec.get(9);
+  const real includemargin = pair_includemargin[p];
+  if (dist >= includemargin) return;
+  real pos[3], fin[6], f[9];
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) { pos[k] = rec.get(k); fin[k] = rec.get(3 + k); fin[3 + k] = rec.get(6 + k); }
+  make_frame(fin, f);
+  const int b1 = pair_b1[p], b2 = pair_b2[p];
+  const int dim = pair_dim[p];
+  const unsigned m1lo = body_dofmask_lo[b1], m2lo = body_dofmask_lo[b2];
+  const unsigned m1hi = body_dofmask_hi[b1], m2hi = body_dofmask_hi[b2];
+  // offsets of the contact point from the subtree-root CoM of each body
+  real off1[3] = {0, 0, 0}, off2[3] = {0, 0, 0};
+  const int r1 = body_rootidx[b1], r2 = body_rootidx[b2];
+  DMC_UNROLL
+  for (int r = 0; r < NROOT; r++) {
+    const real* com = E.subtree_com + 3*root_body[r];
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      if (r1 == r) off1[k] = pos[k] - com[k];
+      if (r2 == r) off2[k] = pos[k] - com[k];
+    }
+  }
+  const real pm = dist - includemargin;
+  const real imp = impedance(pair_solimp + 5*p, pm);
+  const real K = pair_K[p], B = pair_B[p];
+  // translational basis rows (normal, tangent 1, tangent 2)
+  real jb[3][NVX];
+  DMC_UNROLL
+  for (int d = 0; d < 3; d++) {
+    const real* dir = f + 3*d;
+    real w1[3], w2[3];
+    cross3(w1, off1, dir);
+    cross3(w2, off2, dir);
+    DMC_UNROLL
+    for (int j = 0; j < NV; j++) {
+      const bool in1 = ((j < 32 ? m1lo >> j : m1hi >> (j - 32)) & 1u) != 0;
+      const bool in2 = ((j < 32 ? m2lo >> j : m2hi >> (j - 32)) & 1u) != 0;
+      const real* cd = E.cdof + 6*j;
+      const real dl = dot3(dir, cd + 3);
+      const real v2 = dl + dot3(w2, cd), v1 = dl + dot3(w1, cd);
+      jb[d][j] = (in2 ? v2 : R(0)) - (in1 ? v1 : R(0));
+    }
+  }
+  if (dim == 1) {
+    const real Rr = (1 - imp)*pair_diag[6*p]/imp;
+    push_row(E, W, jb[0], pm, K, B, imp, Rr);
+    return;
+  }
+  // pyramidal: every edge gets 2 mu0^2 R(first edge)
+  const real mu0 = pair_friction[5*p];
+  real R0 = (1 - imp)*pair_diag[6*p + 1]/imp;
+  if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
+  const real Rpy = 2*mu0*mu0*R0;
+  DMC_UNROLL
+  for (int k = 1; k < 3; k++) {
+    const real mu = pair_friction[5*p + k - 1];
+    real row[NVX];
+    DMC_UNROLL
+    for (int j = 0; j < NV; j++) row[j] = jb[0][j] + mu*jb[k][j];
+    push_row(E, W, row, pm, K, B, imp, Rpy);
+    DMC_UNROLL
+    for (int j = 0; j < NV; j++) row[j] = jb[0][j] - mu*jb[k][j];
+    push_row(E, W, row, pm, K, B, imp, Rpy);
+  }
+  if (dim > 3) {   // torsional / rolling edges: rotational Jacobian rows
+    DMC_UNROLL
+    for (int k = 3; k < 6; k++) {
+      if (k >= dim) continue;
+      const real* dir = f + 3*(k - 3);
+      const real mu = pair_friction[5*p + k - 1];
+      real jt[NVX], row[NVX];
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) {
+        const bool in1 = ((j < 32 ? m1lo >> j : m1hi >> (j - 32)) & 1u) != 0;
+        const bool in2 = ((j < 32 ? m2lo >> j : m2hi >> (j - 32)) & 1u) != 0;
+        const real v = dot3(dir, E.cdof + 6*j);
+        jt[j] = (in2 ? v : R(0)) - (in1 ? v : R(0));
+      }
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) row[j] = jb[0][j] + mu*jt[j];
+      push_row(E, W, row, pm, K, B, imp, Rpy);
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) row[j] = jb[0][j] - mu*jt[j];
+      push_row(E, W, row, pm, K, B, imp, Rpy);
+    }
+  }
+}
+
+DEV void contact_rows(Env& E, const Work& W) {
+  detect_contacts(E, W);
+  const int n1 = E.ncon < LDS_CONS ? E.ncon : LDS_CONS;
+  for (int k = 0; k < n1; k++) rows_of_contact(E, W, W.lcon(k));
+  if (LDS_CONS < NCON_MAX)
+    for (int k = LDS_CONS; k < E.ncon; k++) rows_of_contact(E, W, W.gcon(k));
 }
 
 // ---------------------------------------------------------------------------
@@ -1205,6 +1305,14 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
       DMC_UNROLL
       for (int i = 0; i < NV; i++) qacc[i] = E.qacc[i];
     }
+#ifdef DMC_DEBUG_EULER_QACC
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) E.qacc[i] = qacc[i];
+#endif
+#ifdef DMC_DEBUG_EULER_RHS
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) E.qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
+#endif
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qvel[i] += h*qacc[i];
     integrate_pos(E.qpos, E.qvel, h);
@@ -1434,7 +1542,10 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate) {
 
 // nsub x Physics.step, then observation + reward of the new state.
 // flags bit0: ctrl given (else reuse ctrl_store); bit1: skip outputs (settle)
-extern "C" __global__ void __launch_bounds__(64, 1)
+#ifndef DMC_WAVES_PER_EU
+#define DMC_WAVES_PER_EU 1
+#endif
+extern "C" __global__ void __launch_bounds__(64, DMC_WAVES_PER_EU)
 dmc_step(DmcArgs a) {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= a.nenv) return;
@@ -1460,7 +1571,7 @@ dmc_step(DmcArgs a) {
     DMC_UNROLL
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
-  __shared__ real lds_rows[(LDS_ROWS > 0 ? LDS_ROWS : 1)*RW*64];
+  __shared__ real lds_rows[LDS_WORDS];
   Work W = {lds_rows + threadIdx.x, a.ws + e, n};
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
   for (int s = 0; s < a.nsub; s++) physics_step(E, W, time, tol);
@@ -1478,7 +1589,7 @@ dmc_step(DmcArgs a) {
 }
 
 // observation / reward / sensors of the current state (reset, after_reset)
-extern "C" __global__ void __launch_bounds__(64, 1)
+extern "C" __global__ void __launch_bounds__(64, DMC_WAVES_PER_EU)
 dmc_observe(DmcArgs a) {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= a.nenv) return;
@@ -1490,10 +1601,10 @@ dmc_observe(DmcArgs a) {
   for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   observe_stage(E, time);
   if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
-    __shared__ real lds_rows[(LDS_ROWS > 0 ? LDS_ROWS : 1)*RW*64];
+    __shared__ real lds_rows[LDS_WORDS];
     Work W = {lds_rows + threadIdx.x, a.ws + e, n};
     E.ncon = 0; E.nefc = 0;
-    if (NPAIR > 0) contact_rows(E, W);
+    if (NPAIR > 0) detect_contacts(E, W);
   }
   store_outputs(E, a, e, false);
   store_env(E, a, e, time);
@@ -1582,5 +1693,5 @@ dmc_init_episode(DmcArgs a) {
 // self-description read by dmc_api.cpp through hipModuleGetGlobal
 extern "C" __device__ const int dmc_info[16] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
-    (NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 1)*RW /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
+    (GLB_ROWS*RW + GLB_CONS*CW > 0 ? GLB_ROWS*RW + GLB_CONS*CW : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
     INTEGRATOR, NPAIR, 0, 0};

@@ -234,9 +234,10 @@ class Physics(_control.Physics):
   """Batched simulation of one compiled MJCF on one MI355X."""
 
   _TASK = codegen.TASK_NONE   # domain subclasses select the fused task
+  _BUILD_MODE = 'auto'        # see build.build_model
 
   def __init__(self, model, batch_size=None, device=0, precision='f32',
-               task=None, ncon_max=None):
+               task=None, ncon_max=None, build_mode=None):
     self.model = model
     self._squeeze = batch_size is None
     self._batch_size = 1 if batch_size is None else int(batch_size)
@@ -247,7 +248,9 @@ class Physics(_control.Physics):
     self._warnings_cause_exception = True
     self._pending_ctrl = None
     self._dirty = True
-    path = build.build_model(model, self._task_id, precision, ncon_max)
+    self._build_mode = build_mode or self._BUILD_MODE
+    path = build.build_model(model, self._task_id, precision, ncon_max,
+                             mode=self._build_mode)
     self._hip_model = wrapper.HipModel(path, device)
     self._batch = wrapper.HipBatch(self._hip_model, self._batch_size)
     self.data = _Data(self)
@@ -417,7 +420,7 @@ class Physics(_control.Physics):
     Physics.__init__(new, self.model,
                      None if self._squeeze else self._batch_size,
                      self._device, self._precision, self._task_id,
-                     self._ncon_max)
+                     self._ncon_max, self._build_mode)
     new._batch.copy_state_from(self._batch)
     new._warn_seen = self._warn_seen.copy()
     new._dirty = self._dirty

@@ -10,7 +10,8 @@ ASSETS = {}
 
 # Keys of `environment_kwargs` consumed by the batched Physics rather than by
 # `control.Environment`.
-PHYSICS_KWARGS = ('batch_size', 'device', 'precision', 'ncon_max')
+PHYSICS_KWARGS = ('batch_size', 'device', 'precision', 'ncon_max',
+                  'build_mode')
 TASK_KWARGS = ('device_init',)
 
 

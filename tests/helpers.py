@@ -11,6 +11,8 @@ MODELS_DIR = os.path.join(os.path.dirname(os.path.dirname(
     os.path.abspath(__file__))), 'dm_control_amd', 'suite', 'models')
 TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
          'humanoid': codegen.TASK_HUMANOID}
+# build mode per suite model (humanoid: see suite/humanoid.py)
+MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'unrolled'}
 
 
 def load_model(name):

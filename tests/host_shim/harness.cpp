@@ -1,0 +1,38 @@
+// Runs dmc_step for ONE env on the host under sanitizers and prints qpos/qvel
+// after each step (compared with the oracle by tests/test_kernel_sanitizers.py).
+#include "shim.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include DMC_KERNEL_SOURCE
+
+int main(int argc, char** argv) {
+  const int steps = argc > 1 ? atoi(argv[1]) : 5;
+  const int nq = NQ > 0 ? NQ : 1, nv = NV > 0 ? NV : 1, nu = NU > 0 ? NU : 1;
+  std::vector<real> qpos(nq), qvel(nv, 0), warm(nv, 0), tm(1, 0), ctrl(nu, 0),
+      obs(NOBS > 0 ? NOBS : 1), rew(1), ret(1), sens(NSENSORDATA > 0 ? NSENSORDATA : 1),
+      xpos(NBODY*3), xmat(NBODY*9), qacc(nv),
+      ws((GLB_ROWS*RW + GLB_CONS*CW > 0 ? GLB_ROWS*RW + GLB_CONS*CW : 1));
+  std::vector<unsigned> warn(1, 0);
+  std::vector<int> stats(3, 0);
+  for (int i = 0; i < NQ; i++) qpos[i] = (real)qpos0[i];
+  // optional initial state from argv: qpos then qvel
+  for (int i = 0; i < NQ && 2 + i < argc; i++) qpos[i] = (real)atof(argv[2 + i]);
+  for (int i = 0; i < NV && 2 + NQ + i < argc; i++) qvel[i] = (real)atof(argv[2 + NQ + i]);
+  DmcArgs a;
+  memset(&a, 0, sizeof a);
+  a.nenv = 1; a.nsub = 1; a.flags = 0;
+  a.qpos = qpos.data(); a.qvel = qvel.data(); a.warm = warm.data(); a.time = tm.data();
+  a.ctrl_store = ctrl.data(); a.obs = obs.data(); a.obs_sk = 1; a.obs_se = NOBS;
+  a.reward = rew.data(); a.episode_return = ret.data(); a.sensordata = sens.data();
+  a.xpos = xpos.data(); a.xmat = xmat.data(); a.qacc = qacc.data();
+  a.warn = warn.data(); a.stats = stats.data(); a.ws = ws.data();
+  for (int t = 0; t < steps; t++) {
+    dmc_step(a);
+    printf("STEP %d", t);
+    for (int i = 0; i < NQ; i++) printf(" %.17g", (double)qpos[i]);
+    for (int i = 0; i < NV; i++) printf(" %.17g", (double)qvel[i]);
+    printf(" | %d %d %d %u\n", stats[0], stats[1], stats[2], warn[0]);
+  }
+  return 0;
+}

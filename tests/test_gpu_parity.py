@@ -36,8 +36,8 @@ pytestmark = pytest.mark.gpu
 W = wrapper
 
 
-def _device_batch(model, task, precision, nenv):
-  hm = W.HipModel(build.build_model(model, task, precision))
+def _device_batch(model, task, precision, nenv, mode='auto'):
+  hm = W.HipModel(build.build_model(model, task, precision, mode=mode))
   return hm, W.HipBatch(hm, nenv)
 
 
@@ -64,7 +64,8 @@ def _degenerate(d, model):
 
 def _teacher_forced(name, precision, nenv, steps, nsub):
   model = helpers.load_model(name)
-  hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv)
+  hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv,
+                         helpers.MODES[name])
   qpos, qvel = helpers.initial_states(model, name, nenv, seed=7)
   om, datas = _oracle_envs(model, qpos, qvel)
   rs = np.random.RandomState(11)
@@ -110,7 +111,8 @@ def test_fp32_build_matches_oracle_per_step(name, nsub):
 
 def _free_run(name, precision, nenv, steps, nsub):
   model = helpers.load_model(name)
-  hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv)
+  hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv,
+                         helpers.MODES[name])
   qpos, qvel = helpers.initial_states(model, name, nenv, seed=3)
   om, datas = _oracle_envs(model, qpos, qvel)
   hb.set_state(qpos.T, qvel.T)
