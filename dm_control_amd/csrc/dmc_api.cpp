@@ -61,6 +61,7 @@ struct dmc_batch {
   void* ctrl_staging = nullptr;   // device copy of host-provided controls
   size_t ctrl_staging_bytes = 0;
   int task_param_i = 0;
+  bool aux_outputs = false;
   double task_param_r[4] = {0, 0, 0, 0};
   // timing
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -98,9 +99,9 @@ void fill_args(dmc_batch* b, DmcArgs& a) {
   a.reward = b->field[DMC_FIELD_REWARD];
   a.episode_return = b->field[DMC_FIELD_RETURN];
   a.sensordata = b->field[DMC_FIELD_SENSORDATA];
-  a.xpos = b->field[DMC_FIELD_XPOS];
-  a.xmat = b->field[DMC_FIELD_XMAT];
-  a.qacc = b->field[DMC_FIELD_QACC];
+  a.xpos = b->aux_outputs ? b->field[DMC_FIELD_XPOS] : nullptr;
+  a.xmat = b->aux_outputs ? b->field[DMC_FIELD_XMAT] : nullptr;
+  a.qacc = b->aux_outputs ? b->field[DMC_FIELD_QACC] : nullptr;
   a.warn = (unsigned*)b->field[DMC_FIELD_WARN];
   a.stats = (int*)b->field[DMC_FIELD_STATS];
   a.ws = b->ws;
@@ -239,6 +240,12 @@ void dmc_batch_free(dmc_batch* b) {
 }
 
 int dmc_batch_nenv(const dmc_batch* b) { return b ? b->nenv : 0; }
+
+int dmc_batch_set_aux_outputs(dmc_batch* b, int enabled) {
+  if (!b) return fail("null batch");
+  b->aux_outputs = enabled != 0;
+  return 0;
+}
 
 int dmc_batch_set_task_params(dmc_batch* b, int iparam, const double* r, int nr) {
   if (!b) return fail("null batch");
@@ -379,6 +386,7 @@ int dmc_batch_copy_state(dmc_batch* dst, const dmc_batch* src) {
     HIP_TRY(hipMemcpyAsync(dst->field[f], src->field[f], dst->bytes[f],
                            hipMemcpyDeviceToDevice, dst->stream));
   dst->task_param_i = src->task_param_i;
+  dst->aux_outputs = src->aux_outputs;
   memcpy(dst->task_param_r, src->task_param_r, sizeof dst->task_param_r);
   HIP_TRY(hipStreamSynchronize(dst->stream));
   return 0;

@@ -250,10 +250,13 @@ constexpr int CW = 11;
 #ifndef DMC_CON_LDS
 #define DMC_CON_LDS 12
 #endif
-constexpr int LDS_CONS = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
-constexpr int LDS_ROWS_FIT =
-    (DMC_LDS_BUDGET - LDS_CONS*CW*64*(int)sizeof(real))/(RW*64*(int)sizeof(real));
+constexpr int REC_BYTES = 64*(int)sizeof(real);       // one record word, all lanes
+constexpr int LDS_CONS_WANT = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
+constexpr int LDS_CONS_FIT = (DMC_LDS_BUDGET/2)/(CW*REC_BYTES);   // <= half the budget
+constexpr int LDS_CONS = LDS_CONS_WANT < LDS_CONS_FIT ? LDS_CONS_WANT : LDS_CONS_FIT;
+constexpr int LDS_ROWS_FIT = (DMC_LDS_BUDGET - LDS_CONS*CW*REC_BYTES)/(RW*REC_BYTES);
 constexpr int LDS_ROWS = LDS_ROWS_FIT < NEFC_MAX ? LDS_ROWS_FIT : NEFC_MAX;
+static_assert(LDS_CONS >= 0 && LDS_ROWS >= 0, "LDS budget arithmetic");
 constexpr int GLB_ROWS = NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 0;
 constexpr int GLB_CONS = NCON_MAX - LDS_CONS > 0 ? NCON_MAX - LDS_CONS : 0;
 enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3 };

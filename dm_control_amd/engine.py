@@ -47,14 +47,17 @@ class _Field:
   axis leads (agent layout) and is dropped for an unbatched Physics.
   """
 
-  def __init__(self, physics, field, width=None, writable=None):
+  def __init__(self, physics, field, width=None, writable=None, aux=False):
     self._p = physics
     self._f = field
     self._width = width
     self._writable = writable
+    self._aux = aux
 
   def _get(self):
     p = self._p
+    if self._aux:
+      p._ensure_aux()
     a = p._batch.read(self._f)
     if self._f == wrapper.FIELD_OBS:
       out = a
@@ -162,11 +165,11 @@ class _Data:
     self.qpos = _Field(p, W.FIELD_QPOS, m.nq, 'qpos')
     self.qvel = _Field(p, W.FIELD_QVEL, m.nv, 'qvel')
     self.qacc_warmstart = _Field(p, W.FIELD_WARMSTART, m.nv, 'warmstart')
-    self.qacc = _Field(p, W.FIELD_QACC, m.nv)
+    self.qacc = _Field(p, W.FIELD_QACC, m.nv, aux=True)
     self.ctrl = _Field(p, W.FIELD_CTRL, m.nu)
     self.sensordata = _Field(p, W.FIELD_SENSORDATA, m.nsensordata)
-    self.xpos = _Field(p, W.FIELD_XPOS)
-    self.xmat = _Field(p, W.FIELD_XMAT)
+    self.xpos = _Field(p, W.FIELD_XPOS, aux=True)
+    self.xmat = _Field(p, W.FIELD_XMAT, aux=True)
     self._time = _Field(p, W.FIELD_TIME, None, 'time')
     self._p = p
 
@@ -248,6 +251,7 @@ class Physics(_control.Physics):
     self._warnings_cause_exception = True
     self._pending_ctrl = None
     self._dirty = True
+    self._aux_on = False
     self._build_mode = build_mode or self._BUILD_MODE
     path = build.build_model(model, self._task_id, precision, ncon_max,
                              mode=self._build_mode)
@@ -352,6 +356,14 @@ class Physics(_control.Physics):
 
   check_divergence = check_invalid_state
 
+  def _ensure_aux(self):
+    """xpos/xmat/qacc are written only once somebody asked for them; from then
+    on every step keeps them current (qacc: from the next step on)."""
+    if not self._aux_on:
+      self._aux_on = True
+      self._batch.set_aux_outputs(True)
+      self.forward()
+
   # -- fused task outputs ---------------------------------------------------------
   def _ensure_outputs(self):
     if self._dirty:
@@ -424,6 +436,7 @@ class Physics(_control.Physics):
     new._batch.copy_state_from(self._batch)
     new._warn_seen = self._warn_seen.copy()
     new._dirty = self._dirty
+    new._aux_on = self._aux_on
     return new
 
   def set_task_params(self, iparam=0, rparams=()):

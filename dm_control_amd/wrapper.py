@@ -48,6 +48,7 @@ SIGNATURES = {
     'dmc_batch_create': (_ci, [_vp, _ci, ctypes.POINTER(_vp)]),
     'dmc_batch_free': (None, [_vp]),
     'dmc_batch_nenv': (_ci, [_vp]),
+    'dmc_batch_set_aux_outputs': (_ci, [_vp, _ci]),
     'dmc_batch_set_task_params': (
         _ci, [_vp, _ci, ctypes.POINTER(ctypes.c_double), _ci]),
     'dmc_batch_reset': (_ci, [_vp]),
@@ -186,6 +187,9 @@ class HipBatch:
     _check(self._lib.dmc_batch_set_state(
         self.ptr, prep(qpos, FIELD_QPOS), prep(qvel, FIELD_QVEL),
         prep(warmstart, FIELD_WARMSTART), prep(time, FIELD_TIME)))
+
+  def set_aux_outputs(self, enabled):
+    _check(self._lib.dmc_batch_set_aux_outputs(self.ptr, int(bool(enabled))))
 
   def set_task_params(self, iparam=0, rparams=()):
     arr = (ctypes.c_double*4)(*(list(rparams) + [0.0]*4)[:4])

@@ -90,6 +90,11 @@ int dmc_batch_create(const dmc_model* model, int nenv, dmc_batch** out);
 void dmc_batch_free(dmc_batch* batch);
 int dmc_batch_nenv(const dmc_batch* batch);
 
+/* auxiliary per-step outputs (DMC_FIELD_XPOS, _XMAT, _QACC).  Off by default:
+ * they are 105 extra words per env-step for cheetah, three times the
+ * algorithmic output; switch them on when the caller reads those fields. */
+int dmc_batch_set_aux_outputs(dmc_batch* batch, int enabled);
+
 /* task parameters: integer flags + up to 4 reals (meaning is per task, e.g.
  * cartpole {bit0 sparse, bit1 swing_up}; humanoid r[0] = move_speed) */
 int dmc_batch_set_task_params(dmc_batch* batch, int iparam, const double* rparam,

@@ -191,6 +191,7 @@ def test_known_answer_models_on_device(key):
   assert touched                              # the contact path was exercised
   if key == 'readme_box':
     # K1 on the device: env 0 starts at rest, settles at the README height
+    hb.set_aux_outputs(True)
     for _ in range(350):
       hb.step_host(None, 1)
     z = hb.read(W.FIELD_XPOS).T[0].reshape(-1, 3)[1, 2]
