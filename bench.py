@@ -40,6 +40,22 @@ def algorithmic_bytes_per_env_step(info, real_size):
   return (reads + writes)*real_size
 
 
+def measured_traffic(domain, task, batch, precision):
+  """HBM bytes per launch from the committed PMC summary of this workload.
+
+  rocprofv3 counters cannot be collected from inside the timed run; they come
+  from separate `--pmc` passes of this same script (profiles/README.md) and
+  are only reported for the exact workload they were measured on.
+  """
+  path = os.path.join(_ROOT, 'profiles', 'r01_pmc_%s_%s_b%d_%s.json'
+                      % (domain, task, batch, precision))
+  try:
+    with open(path) as f:
+      return json.load(f)['traffic_bytes_per_launch']
+  except (OSError, ValueError, KeyError):
+    return None
+
+
 def usable_cores():
   """Host cores this process may actually use (affinity and cgroup quota)."""
   n = os.cpu_count() or 1
@@ -225,7 +241,11 @@ def main():
         'roofline': {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS,
-            'traffic': None, 'kernel': 'dmc_step',
+            'traffic': measured_traffic(args.domain, args.task, args.batch,
+                                        args.precision),
+            'traffic_unit': 'bytes/launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, '
+                            'separate passes, see profiles/)',
+            'kernel': 'dmc_step',
             'kernel_ms_avg': kernel_ms,
             'algorithmic_bytes_per_launch': bytes_per_launch},
         'mean_episode_return': float(returns.mean().item()),

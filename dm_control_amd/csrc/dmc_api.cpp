@@ -14,6 +14,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -38,8 +39,10 @@ int fail(const char* fmt, ...) {
 #define HIP_TRY(expr)                                                        \
   do {                                                                       \
     hipError_t err_ = (expr);                                                \
-    if (err_ != hipSuccess)                                                  \
+    if (err_ != hipSuccess) {                                                \
+      (void)hipGetLastError(); /* do not leak sticky state to other users */ \
       return fail("%s failed: %s", #expr, hipGetErrorString(err_));          \
+    }                                                                        \
   } while (0)
 
 }  // namespace
@@ -54,7 +57,8 @@ struct dmc_model {
 struct dmc_batch {
   const dmc_model* model = nullptr;
   int nenv = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // stream in use (own or caller's)
+  hipStream_t own_stream = nullptr;   // created with the batch
   void* field[DMC_FIELD_COUNT] = {};
   size_t bytes[DMC_FIELD_COUNT] = {};
   void* ws = nullptr;
@@ -75,7 +79,14 @@ int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args) {
   size_t size = sizeof(DmcArgs);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args,
                     HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  const unsigned block = 64;   // one wavefront per workgroup
+  // One full wavefront per workgroup.  Measured at 8192 envs (cheetah): 64
+  // lanes/wave on 128 CUs 0.0787 ms, 32 lanes on 256 CUs 0.0828 ms, 16 lanes
+  // 0.152 ms -- thinner waves do not pay.  DMC_BLOCK overrides (experiments).
+  unsigned block = 64;
+  if (const char* env = getenv("DMC_BLOCK")) {
+    const int v = atoi(env);
+    if (v == 16 || v == 32 || v == 64) block = (unsigned)v;
+  }
   const unsigned grid = (unsigned)((b->nenv + block - 1)/block);
   HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, b->stream,
                                 nullptr, config));
@@ -138,6 +149,7 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   hipError_t err = hipModuleLoad(&m->module, path);
   if (err != hipSuccess) {
     delete m;
+    (void)hipGetLastError();   // clear the runtime's sticky last-error
     return fail("hipModuleLoad(%s) failed: %s", path, hipGetErrorString(err));
   }
   struct { const char* name; hipFunction_t* fn; } fns[] = {
@@ -148,6 +160,7 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
     if (err != hipSuccess) {
       (void)hipModuleUnload(m->module);
       delete m;
+      (void)hipGetLastError();
       return fail("code object %s lacks kernel %s", path, f.name);
     }
   }
@@ -209,7 +222,8 @@ int dmc_batch_create(const dmc_model* model, int nenv, dmc_batch** out) {
   b->bytes[DMC_FIELD_WARN] = n*sizeof(unsigned);
   b->bytes[DMC_FIELD_STATS] = 3*n*sizeof(int);
   b->bytes[DMC_FIELD_RETURN] = n*rs;
-  hipError_t err = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+  hipError_t err = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
+  b->stream = b->own_stream;
   for (int f = 0; f < DMC_FIELD_COUNT && err == hipSuccess; f++) {
     err = hipMalloc(&b->field[f], b->bytes[f]);
     if (err == hipSuccess) err = hipMemset(b->field[f], 0, b->bytes[f]);
@@ -220,6 +234,7 @@ int dmc_batch_create(const dmc_model* model, int nenv, dmc_batch** out) {
   if (err == hipSuccess) err = hipEventCreate(&b->ev1);
   if (err != hipSuccess) {
     dmc_batch_free(b);
+    (void)hipGetLastError();
     return fail("dmc_batch_create: %s", hipGetErrorString(err));
   }
   *out = b;
@@ -235,7 +250,7 @@ void dmc_batch_free(dmc_batch* b) {
   if (b->ctrl_staging) (void)hipFree(b->ctrl_staging);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
   delete b;
 }
 
@@ -396,6 +411,14 @@ int dmc_batch_sync(dmc_batch* b) {
   if (!b) return fail("null batch");
   HIP_TRY(hipSetDevice(b->model->device));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int dmc_batch_set_stream(dmc_batch* b, void* stream, int external) {
+  if (!b) return fail("null batch");
+  HIP_TRY(hipSetDevice(b->model->device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->stream = external ? (hipStream_t)stream : b->own_stream;
   return 0;
 }
 

@@ -12,6 +12,7 @@ device is present, construction raises `Error`.
 
 import ctypes
 import os
+import sys
 
 import numpy as np
 
@@ -63,6 +64,7 @@ SIGNATURES = {
     'dmc_batch_copy_state': (_ci, [_vp, _vp]),
     'dmc_batch_sync': (_ci, [_vp]),
     'dmc_batch_stream': (_vp, [_vp]),
+    'dmc_batch_set_stream': (_ci, [_vp, _vp, _ci]),
     'dmc_batch_timer_start': (_ci, [_vp]),
     'dmc_batch_timer_stop': (_ci, [_vp, ctypes.POINTER(ctypes.c_double),
                                    ctypes.POINTER(_cll)]),
@@ -80,6 +82,15 @@ def get_lib():
   global _lib
   if _lib is not None:
     return _lib
+  # PyTorch-ROCm wheels bundle their own libamdhip64 (same SONAME as the
+  # system one libdmc_hip.so links to).  Whichever is mapped first serves the
+  # whole process, and torch fails to find devices when the system runtime got
+  # there first, so let torch map its copy before ours when it is installed.
+  if 'torch' not in sys.modules and not os.environ.get('DMC_NO_TORCH_PRELOAD'):
+    try:
+      import torch  # noqa: F401  pylint: disable=unused-import,g-import-not-at-top
+    except ImportError:
+      pass
   path = get_lib_path()
   if not os.path.exists(path):
     raise Error('HIP extension not found at {!r}; run '
@@ -231,6 +242,15 @@ class HipBatch:
 
   def stream(self):
     return self._lib.dmc_batch_stream(self.ptr)
+
+  def set_stream(self, stream_ptr, external=True):
+    """Runs later launches on a caller-owned hipStream_t.
+
+    `stream_ptr` 0/None with external=True is HIP's default (null) stream;
+    external=False restores the batch's own stream.
+    """
+    _check(self._lib.dmc_batch_set_stream(self.ptr, stream_ptr or None,
+                                          int(external)))
 
   def sync(self):
     _check(self._lib.dmc_batch_sync(self.ptr))

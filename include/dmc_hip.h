@@ -131,6 +131,12 @@ void* dmc_batch_device_ptr(dmc_batch* batch, int field);
 int dmc_batch_clear_warnings(dmc_batch* batch);
 int dmc_batch_copy_state(dmc_batch* dst, const dmc_batch* src);
 int dmc_batch_sync(dmc_batch* batch);
+/* run every later launch/copy of this batch on a caller-owned hipStream_t (for
+ * example torch.cuda.current_stream().cuda_stream, so the step is ordered with
+ * the caller's own kernels without extra synchronisation).  external != 0:
+ * use `stream` as given (NULL is HIP's legacy default stream, which is what
+ * torch's default stream is); external == 0: back to the batch's own stream */
+int dmc_batch_set_stream(dmc_batch* batch, void* stream, int external);
 /* the batch's hipStream_t, for callers that enqueue their own work behind the
  * step (e.g. torch.cuda.ExternalStream) */
 void* dmc_batch_stream(dmc_batch* batch);

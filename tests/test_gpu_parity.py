@@ -412,3 +412,48 @@ def test_c_abi_argument_errors():
     hb.step_host(np.zeros((3, 1)))
   hb.step_host(None, 0)       # zero substeps: state unchanged, outputs refreshed
   np.testing.assert_array_equal(hb.read(W.FIELD_QPOS)[:, 0], model.qpos0)
+
+
+def test_vec_env_numpy_and_torch_modes():
+  """scripts/vec_env.py calling convention: stacked obs, auto-reset with
+  `terminal_observation` (:346-352); torch mode aliases device buffers."""
+  import torch
+  from dm_control_amd import vec_env
+  n = 64
+  env = vec_env.VecEnv('cartpole', 'swingup', n, seed=3,
+                       task_kwargs={'time_limit': 0.05})
+  obs = env.reset()
+  assert obs.shape == (n, 5) and env.action_dim == 1
+  rs = np.random.RandomState(0)
+  for t in range(5):
+    obs, rew, done, infos = env.step(rs.uniform(-1, 1, (n, 1)))
+    assert obs.shape == (n, 5) and rew.shape == (n,) and done.shape == (n,)
+    assert done.all() == (t == 4)
+  assert 'terminal_observation' in infos[0] and len(infos) == n
+  assert not np.array_equal(infos[0]['terminal_observation'], obs[0])
+  env.close()
+
+  tenv = vec_env.VecEnv('cheetah', 'run', n, seed=3, torch_io=True)
+  obs = tenv.reset()
+  assert obs.is_cuda and tuple(obs.shape) == (n, 17)
+  ref = vec_env.VecEnv('cheetah', 'run', n, seed=3,
+                       environment_kwargs={'device_init': True})
+  ref_obs = ref.reset()
+  np.testing.assert_array_equal(obs.cpu().numpy().astype(np.float64), ref_obs)
+  gen = torch.Generator(device='cuda').manual_seed(0)
+  for _ in range(4):
+    act = torch.rand(n, 6, device='cuda', generator=gen)*2 - 1
+    obs, rew, done, infos = tenv.step(act)
+    robs, rrew, rdone, _ = ref.step(act.cpu().numpy())
+    torch.cuda.synchronize()
+    # the same physics whether actions arrive by pointer or by host copy
+    np.testing.assert_array_equal(obs.cpu().numpy().astype(np.float64), robs)
+    np.testing.assert_array_equal(rew.cpu().numpy().astype(np.float64), rrew)
+    assert not bool(done.any())
+  # column-major action tensor: read through strides, no copy needed
+  act = (torch.rand(6, n, device='cuda', generator=gen)*2 - 1).t()
+  obs, _, _, _ = tenv.step(act)
+  robs, _, _, _ = ref.step(act.cpu().numpy())
+  np.testing.assert_array_equal(obs.cpu().numpy().astype(np.float64), robs)
+  tenv.close()
+  ref.close()
