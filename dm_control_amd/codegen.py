@@ -20,6 +20,7 @@ import numpy as np
 from dm_control_amd.mjcf import model as mdl
 
 TASK_NONE, TASK_CARTPOLE, TASK_CHEETAH, TASK_HUMANOID = 0, 1, 2, 3
+TASK_WALKER, TASK_PENDULUM = 4, 5
 
 _SUPPORTED_PAIRS = {
     (mdl.GEOM_PLANE, mdl.GEOM_SPHERE), (mdl.GEOM_PLANE, mdl.GEOM_CAPSULE),
@@ -129,8 +130,10 @@ def _fmt(vals, kind):
 
 
 def task_bodies(m, task):
-  if task == TASK_CHEETAH:
+  if task in (TASK_CHEETAH, TASK_WALKER):
     return [m.name2id('torso', 'body')]
+  if task == TASK_PENDULUM:
+    return [m.name2id('pole', 'body')]
   if task == TASK_HUMANOID:
     return [m.name2id(n, 'body') for n in
             ('torso', 'head', 'left_hand', 'left_foot', 'right_hand',
@@ -145,6 +148,10 @@ def observation_size(m, task):
     return (m.nq - 1) + m.nv
   if task == TASK_HUMANOID:
     return (m.nq - 7) + 1 + 12 + 3 + 3 + m.nv
+  if task == TASK_WALKER:
+    return 2*(m.nbody - 1) + 1 + m.nv
+  if task == TASK_PENDULUM:
+    return 3
   return m.nq + m.nv
 
 

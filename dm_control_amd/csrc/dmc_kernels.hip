@@ -56,6 +56,18 @@ using namespace dmc_model;
 #define DEVN static __device__ __forceinline__
 
 constexpr int NM = NV*(NV + 1)/2;      // packed lower triangle
+// Optional "big matrix" storage (-DDMC_BIGMAT=1): M in the HBM workspace, its
+// factor / the Newton Hessian in one LDS-resident (fp32) or HBM-resident (fp64)
+// buffer instead of per-lane registers.  Measured on the 27-dof humanoid it is
+// SLOWER with one env per lane (55.8 vs 11.9 ms per launch: the unrolled code's
+// live ranges still overflow the register file, spills rise from 2232 to 3318),
+// so it is off by default; it is the storage layout the several-lanes-per-env
+// solver will use and is kept compiling under the host sanitizers.
+#ifndef DMC_BIGMAT
+#define DMC_BIGMAT 0
+#endif
+constexpr bool BIGMAT = DMC_BIGMAT != 0 && NM > 0;
+constexpr int MAT_REGS = BIGMAT ? 1 : (NM > 0 ? NM : 1);
 constexpr int NVX = NV > 0 ? NV : 1;
 constexpr int NUX = NU > 0 ? NU : 1;
 constexpr real MAXVAL = R(1e10);
@@ -69,7 +81,8 @@ enum { DSBL_CONSTRAINT = 1 << 0, DSBL_LIMIT = 1 << 3, DSBL_CONTACT = 1 << 4,
 enum { WARN_INERTIA = 1, WARN_CONTACTFULL = 2, WARN_CNSTRFULL = 4,
        WARN_BADQPOS = 16, WARN_BADQVEL = 32, WARN_BADQACC = 64,
        WARN_BADCTRL = 128 };
-enum { TASK_NONE = 0, TASK_CARTPOLE = 1, TASK_CHEETAH = 2, TASK_HUMANOID = 3 };
+enum { TASK_NONE = 0, TASK_CARTPOLE = 1, TASK_CHEETAH = 2, TASK_HUMANOID = 3,
+       TASK_WALKER = 4, TASK_PENDULUM = 5 };
 
 #define DMC_REALPTR real*
 #define DMC_CREALPTR const real*
@@ -170,52 +183,88 @@ DEV real dot6(const real* a, const real* b) {
 }
 DEV int tri(int i, int j) { return i*(i + 1)/2 + j; }   // i >= j
 
+// Packed symmetric nv x nv matrices behind one accessor interface:
+//   RegMat  per-lane register array (small models: everything static)
+//   LdsMat  [entry][lane] in LDS     (nv ~ 27: 378 entries do not fit in VGPRs
+//   GlbMat  [entry][env] in HBM       next to the rest of the working set)
+struct RegMat {
+  real* v;
+  __device__ __forceinline__ real get(int i) const { return v[i]; }
+  __device__ __forceinline__ void set(int i, real x) const { v[i] = x; }
+};
+struct LdsMat {
+  real* p;
+  __device__ __forceinline__ real get(int i) const { return p[i*64]; }
+  __device__ __forceinline__ void set(int i, real x) const { p[i*64] = x; }
+};
+struct GlbMat {
+  real* p; long long n;
+  __device__ __forceinline__ real get(int i) const { return p[i*n]; }
+  __device__ __forceinline__ void set(int i, real x) const { p[i*n] = x; }
+};
+
 // y = A x for packed symmetric A
-DEV void symv(real* y, const real* A, const real* x) {
+template <class Mat>
+DEV void symv(real* y, const Mat& A, const real* x) {
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) y[i] = 0;
+  // one pass over the stored triangle: entry (i, j) feeds y[i] and y[j]
   DMC_UNROLL
   for (int i = 0; i < NV; i++) {
-    real s = 0;
     DMC_UNROLL
-    for (int j = 0; j < NV; j++) s += A[i >= j ? tri(i, j) : tri(j, i)]*x[j];
-    y[i] = s;
+    for (int j = 0; j <= i; j++) {
+      const real a = A.get(tri(i, j));
+      y[i] += a*x[j];
+      if (j != i) y[j] += a*x[i];
+    }
   }
 }
 // in-place packed Cholesky A = L L^T; the diagonal slots hold 1/L_jj so the
 // triangular solves multiply instead of divide; returns clamped pivots
-DEV int chol_factor(real* A) {
+template <class Mat>
+DEV int chol_factor_t(const Mat& A) {
   int nbad = 0;
   DMC_UNROLL
   for (int j = 0; j < NV; j++) {
-    real s = A[tri(j, j)];
+    real rowj[NVX];               // row j of L, columns < j, read once
+    real s = A.get(tri(j, j));
     DMC_UNROLL
-    for (int k = 0; k < j; k++) s -= A[tri(j, k)]*A[tri(j, k)];
+    for (int k = 0; k < j; k++) { rowj[k] = A.get(tri(j, k)); s -= rowj[k]*rowj[k]; }
     if (!(s >= DMC_MINVAL)) { s = DMC_MINVAL; nbad++; }
     const real inv = rsqrt_(s);
-    A[tri(j, j)] = inv;
+    A.set(tri(j, j), inv);
     DMC_UNROLL
     for (int i = j + 1; i < NV; i++) {
-      real t = A[tri(i, j)];
+      real t = A.get(tri(i, j));
       DMC_UNROLL
-      for (int k = 0; k < j; k++) t -= A[tri(i, k)]*A[tri(j, k)];
-      A[tri(i, j)] = t*inv;
+      for (int k = 0; k < j; k++) t -= A.get(tri(i, k))*rowj[k];
+      A.set(tri(i, j), t*inv);
     }
   }
   return nbad;
 }
-DEV void chol_solve(real* x, const real* L) {
+// shared out-of-line copies for the memory-resident forms (three call sites)
+static __device__ __noinline__ int chol_factor_lds(real* p) { return chol_factor_t(LdsMat{p}); }
+static __device__ __noinline__ int chol_factor_glb(real* p, long long n) { return chol_factor_t(GlbMat{p, n}); }
+DEV int chol_factor(const RegMat& A) { return chol_factor_t(A); }
+DEV int chol_factor(const LdsMat& A) { return chol_factor_lds(A.p); }
+DEV int chol_factor(const GlbMat& A) { return chol_factor_glb(A.p, A.n); }
+
+template <class Mat>
+DEV void chol_solve(real* x, const Mat& L) {
   DMC_UNROLL
   for (int i = 0; i < NV; i++) {
     real s = x[i];
     DMC_UNROLL
-    for (int k = 0; k < i; k++) s -= L[tri(i, k)]*x[k];
-    x[i] = s*L[tri(i, i)];
+    for (int k = 0; k < i; k++) s -= L.get(tri(i, k))*x[k];
+    x[i] = s*L.get(tri(i, i));
   }
   DMC_UNROLL
   for (int i = NV - 1; i >= 0; i--) {
     real s = x[i];
     DMC_UNROLL
-    for (int k = i + 1; k < NV; k++) s -= L[tri(k, i)]*x[k];
-    x[i] = s*L[tri(i, i)];
+    for (int k = i + 1; k < NV; k++) s -= L.get(tri(k, i))*x[k];
+    x[i] = s*L.get(tri(i, i));
   }
 }
 
@@ -230,7 +279,7 @@ struct Env {
   real subtree_com[NBODY*3];
   real cinert[NBODY*10];
   real cdof[NVX*6], cdof_dot[NVX*6], cvel[NBODY*6];
-  real qM[NM > 0 ? NM : 1], qL[NM > 0 ? NM : 1];
+  real qM[MAT_REGS], qL[MAT_REGS];   // register-resident only in small mode
   real qfrc_smooth[NVX], qfrc_constraint[NVX], qacc_smooth[NVX], qacc[NVX];
   real subtree_linvel[NBODY*3];
   int ncon, nefc, iters;
@@ -245,16 +294,21 @@ struct Env {
 constexpr int RW = NV + 4;
 constexpr int CW = 11;
 #ifndef DMC_LDS_BUDGET
-#define DMC_LDS_BUDGET (128*1024)
+#define DMC_LDS_BUDGET (BIGMAT ? 156*1024 : 128*1024)
 #endif
 #ifndef DMC_CON_LDS
 #define DMC_CON_LDS 12
 #endif
 constexpr int REC_BYTES = 64*(int)sizeof(real);       // one record word, all lanes
-constexpr int LDS_CONS_WANT = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
-constexpr int LDS_CONS_FIT = (DMC_LDS_BUDGET/2)/(CW*REC_BYTES);   // <= half the budget
+// big-matrix mode: the factor/Hessian buffer gets LDS first if it leaves room
+constexpr bool MAT_IN_LDS = BIGMAT && NM*REC_BYTES + 4*(RW + CW)*REC_BYTES <= DMC_LDS_BUDGET;
+constexpr int MAT_LDS_WORDS = MAT_IN_LDS ? NM : 0;
+constexpr int REC_BUDGET = DMC_LDS_BUDGET - MAT_LDS_WORDS*REC_BYTES;
+constexpr int LDS_CONS_WANT0 = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
+constexpr int LDS_CONS_WANT = MAT_IN_LDS && LDS_CONS_WANT0 > 6 ? 6 : LDS_CONS_WANT0;
+constexpr int LDS_CONS_FIT = (REC_BUDGET/2)/(CW*REC_BYTES);   // <= half the budget
 constexpr int LDS_CONS = LDS_CONS_WANT < LDS_CONS_FIT ? LDS_CONS_WANT : LDS_CONS_FIT;
-constexpr int LDS_ROWS_FIT = (DMC_LDS_BUDGET - LDS_CONS*CW*REC_BYTES)/(RW*REC_BYTES);
+constexpr int LDS_ROWS_FIT = (REC_BUDGET - LDS_CONS*CW*REC_BYTES)/(RW*REC_BYTES);
 constexpr int LDS_ROWS = LDS_ROWS_FIT < NEFC_MAX ? LDS_ROWS_FIT : NEFC_MAX;
 static_assert(LDS_CONS >= 0 && LDS_ROWS >= 0, "LDS budget arithmetic");
 constexpr int GLB_ROWS = NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 0;
@@ -271,10 +325,19 @@ struct GlbRow {
   __device__ __forceinline__ real get(int k) const { return p[k*n]; }
   __device__ __forceinline__ void set(int k, real v) const { p[k*n] = v; }
 };
+// workspace words per env: overflow rows, overflow contacts, then (big-matrix
+// mode) M and, if it did not fit in LDS, the factor/Hessian buffer
+constexpr int WS_MAT_M = GLB_ROWS*RW + GLB_CONS*CW;
+constexpr int WS_MAT_L = WS_MAT_M + (BIGMAT ? NM : 0);
+constexpr int WS_WORDS = WS_MAT_L + (BIGMAT && !MAT_IN_LDS ? NM : 0);
+
 struct Work {
-  real* lds;   // LDS base + lane (rows first, then contact records)
-  real* glb;   // workspace base + env (overflow rows, then overflow contacts)
+  real* lds;   // LDS base + lane (rows, contact records, then the matrix buffer)
+  real* glb;   // workspace base + env
   long long nenv;
+  __device__ __forceinline__ GlbMat matM() const { return GlbMat{glb + (long long)WS_MAT_M*nenv, nenv}; }
+  __device__ __forceinline__ LdsMat matL_lds() const { return LdsMat{lds + (LDS_ROWS*RW + LDS_CONS*CW)*64}; }
+  __device__ __forceinline__ GlbMat matL_glb() const { return GlbMat{glb + (long long)WS_MAT_L*nenv, nenv}; }
   __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*64}; }
   __device__ __forceinline__ GlbRow grow(int r) const {
     return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
@@ -286,7 +349,8 @@ struct Work {
     return GlbRow{glb + ((long long)GLB_ROWS*RW + (long long)(k - LDS_CONS)*CW)*nenv, nenv};
   }
 };
-constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW > 0 ? LDS_ROWS*RW + LDS_CONS*CW : 1)*64;
+constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW + MAT_LDS_WORDS > 0
+                           ? LDS_ROWS*RW + LDS_CONS*CW + MAT_LDS_WORDS : 1)*64;
 // f(row handle) for rows [0, nefc): LDS tier first, then the HBM tier
 template <class F>
 static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) {
@@ -295,6 +359,22 @@ static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) 
   if (LDS_ROWS < NEFC_MAX)
     for (int r = LDS_ROWS; r < nefc; r++) f(W.grow(r));
 }
+
+// which storage backs M and the factor/Hessian buffer in this build
+template <bool Big> struct MatSel;
+template <> struct MatSel<false> {
+  static __device__ __forceinline__ RegMat M(Env& E, const Work&) { return RegMat{E.qM}; }
+  static __device__ __forceinline__ RegMat L(Env& E, const Work&) { return RegMat{E.qL}; }
+};
+template <> struct MatSel<true> {
+  static __device__ __forceinline__ GlbMat M(Env&, const Work& W) { return W.matM(); }
+#if 1
+  static __device__ __forceinline__ auto L(Env&, const Work& W) {
+    if constexpr (MAT_IN_LDS) return W.matL_lds(); else return W.matL_glb();
+  }
+#endif
+};
+using Mats = MatSel<BIGMAT>;
 
 // ---------------------------------------------------------------------------
 // position stage: kinematics, centre-of-mass frame, composite inertia
@@ -470,7 +550,9 @@ DEV void com_pos(Env& E) {
 }
 
 // composite rigid body algorithm -> packed M, then M = L L^T
-DEV void crb_factor(Env& E) {
+DEV void crb_factor(Env& E, const Work& W) {
+  const auto M = Mats::M(E, W);
+  const auto L = Mats::L(E, W);
   real crb[NBODY*10];
   DMC_UNROLL
   for (int i = 0; i < NBODY*10; i++) crb[i] = E.cinert[i];
@@ -480,22 +562,22 @@ DEV void crb_factor(Env& E) {
       DMC_UNROLL
       for (int k = 0; k < 10; k++) crb[10*body_parentid[i] + k] += crb[10*i + k];
   DMC_UNROLL
-  for (int i = 0; i < NM; i++) E.qM[i] = 0;
+  for (int i = 0; i < NM; i++) M.set(i, 0);
   DMC_UNROLL
   for (int i = 0; i < NV; i++) {
     real buf[6];
     mul_inert_vec(buf, crb + 10*dof_bodyid[i], E.cdof + 6*i);
-    E.qM[tri(i, i)] = dot6(E.cdof + 6*i, buf) + R(dof_armature[i]);
+    M.set(tri(i, i), dot6(E.cdof + 6*i, buf) + R(dof_armature[i]));
     DMC_UNROLL
     for (int a = 0; a < MAXCHAIN; a++)
       if (a < dof_anc_len[i]) {
         const int j = dof_anc[i*MAXCHAIN + a];
-        E.qM[tri(i, j)] = dot6(E.cdof + 6*j, buf);
+        M.set(tri(i, j), dot6(E.cdof + 6*j, buf));
       }
   }
   DMC_UNROLL
-  for (int i = 0; i < NM; i++) E.qL[i] = E.qM[i];
-  if (chol_factor(E.qL)) E.warn |= WARN_INERTIA;
+  for (int i = 0; i < NM; i++) L.set(i, M.get(i));
+  if (chol_factor(L)) E.warn |= WARN_INERTIA;
 }
 
 // ---------------------------------------------------------------------------
@@ -545,7 +627,7 @@ DEV void com_vel(Env& E) {
 }
 
 // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
-DEV void smooth_forces(Env& E, bool actuation) {
+DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
   real cacc[NBODY*6], cfrc[NBODY*6];
   DMC_UNROLL
   for (int k = 0; k < 6; k++) { cacc[k] = 0; cfrc[k] = 0; }
@@ -610,7 +692,7 @@ DEV void smooth_forces(Env& E, bool actuation) {
   }
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qacc_smooth[i] = E.qfrc_smooth[i];
-  chol_solve(E.qacc_smooth, E.qL);
+  chol_solve(E.qacc_smooth, Mats::L(E, W));
 }
 
 DEV void subtree_vel(Env& E) {
@@ -1082,17 +1164,21 @@ DEV void ls_eval(LsPoint& P, real alpha, const Env& E, const Work& W, real q1, r
 }
 
 DEV void solve_newton(Env& E, const Work& W, real tol) {
-  real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], H[NM > 0 ? NM : 1];
+  real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], Hreg[MAT_REGS];
+  const auto M = Mats::M(E, W);
+  // small mode: Hessian in registers; big mode: it reuses the factor buffer
+  // (the factor of M is dead once qacc_smooth has been solved)
+  const auto H = [&]() { if constexpr (BIGMAT) return Mats::L(E, W); else return RegMat{Hreg}; }();
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
-  symv(Ma, E.qM, E.qacc);
+  symv(Ma, M, E.qacc);
   real improvement = 0;
   bool converged = false;
   int iter = 0;
   for (;; iter++) {
     // active set, forces, gradient and Hessian in one pass over the rows
     DMC_UNROLL
-    for (int i = 0; i < NM; i++) H[i] = E.qM[i];
+    for (int i = 0; i < NM; i++) H.set(i, M.get(i));
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
     for_rows(W, nefc, [&](auto rec) {
@@ -1107,7 +1193,7 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
           E.qfrc_constraint[j] += row[j]*f;
           const real s = D*row[j];
           DMC_UNROLL
-          for (int k = 0; k <= j; k++) H[tri(j, k)] += s*row[k];
+          for (int k = 0; k <= j; k++) H.set(tri(j, k), H.get(tri(j, k)) + s*row[k]);
         }
       }
     });
@@ -1129,7 +1215,7 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
     sn = sqrt(sn);
     if (sn < DMC_MINVAL) break;
     const real gtol = tol*R(0.01)*sn/scale;
-    symv(Mv, E.qM, search);
+    symv(Mv, M, search);
     real q1 = 0, q2 = 0;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) {
@@ -1187,9 +1273,9 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
 DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
   kinematics(E);
   com_pos(E);
-  crb_factor(E);
+  crb_factor(E, W);
   com_vel(E);
-  smooth_forces(E, actuation);
+  smooth_forces(E, W, actuation);
   E.ncon = 0; E.nefc = 0; E.iters = 0;
   limit_rows(E, W);
 #ifndef DMC_ABLATE_CONTACT
@@ -1210,7 +1296,7 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
     real Ma[NVX], cw = 0, cs = 0;
     if (try_warm) {
-      symv(Ma, E.qM, E.warm);
+      symv(Ma, Mats::M(E, W), E.warm);
       DMC_UNROLL
       for (int i = 0; i < NV; i++)
         cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
@@ -1294,12 +1380,14 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
     for (int i = 0; i < NV; i++) damped |= dof_damping[i] > 0;
     real qacc[NVX];
     if (damped) {
-      real A[NM > 0 ? NM : 1];
+      real Areg[MAT_REGS];
+      const auto M = Mats::M(E, W);
+      const auto A = [&]() { if constexpr (BIGMAT) return Mats::L(E, W); else return RegMat{Areg}; }();
       DMC_UNROLL
-      for (int i = 0; i < NM; i++) A[i] = E.qM[i];
+      for (int i = 0; i < NM; i++) A.set(i, M.get(i));
       DMC_UNROLL
       for (int i = 0; i < NV; i++) {
-        A[tri(i, i)] += h*R(dof_damping[i]);
+        A.set(tri(i, i), A.get(tri(i, i)) + h*R(dof_damping[i]));
         qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
       }
       chol_factor(A);
@@ -1483,6 +1571,35 @@ DEV real task_outputs(const Env& E, const DmcArgs& a, real* obs) {
       move = (5*move + 1)/6;
       reward = small_control*standing*upright*move;
     }
+  } else if (TASK == TASK_WALKER) {
+    // walker.py:86-160; task_body[0] = torso
+    const int torso = task_body[0];
+    int o = 0;
+    DMC_UNROLL
+    for (int b = 1; b < NBODY; b++) { OBS(o++) = E.xmat[9*b]; OBS(o++) = E.xmat[9*b + 2]; }
+    const real height = E.xpos[3*torso + 2];
+    OBS(o++) = height;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) OBS(o++) = E.qvel[i];
+    const real standing = tolerance(height, R(1.2), inf, R(0.6), SIG_GAUSSIAN, R(0.1));
+    const real upright = (1 + E.xmat[9*torso + 8])*R(0.5);
+    const real stand_reward = (3*standing + upright)*R(0.25);
+    const real move_speed = R(a.task_param_r[0]);
+    if (move_speed == 0) {
+      reward = stand_reward;
+    } else {
+      const real move = tolerance(E.subtree_linvel[3*torso], move_speed, inf,
+                                  move_speed*R(0.5), SIG_LINEAR, R(0.5));
+      reward = stand_reward*(5*move + 1)/6;
+    }
+  } else if (TASK == TASK_PENDULUM) {
+    // pendulum.py:52-120; task_body[0] = pole; cos(8 deg) bound, margin 0
+    const int pole = task_body[0];
+    OBS(0) = E.xmat[9*pole + 8];
+    OBS(1) = E.xmat[9*pole + 2];
+    OBS(2) = E.qvel[0];
+    reward = tolerance(E.xmat[9*pole + 8], R(0.9902680687415704), R(1), 0,
+                       SIG_GAUSSIAN, R(0.1));
   } else {
     DMC_UNROLL
     for (int i = 0; i < NQ; i++) OBS(i) = E.qpos[i];
@@ -1689,14 +1806,15 @@ dmc_init_episode(DmcArgs a) {
     }
     DMC_UNROLL
     for (int i = 0; i < NV; i++) qvel[i] = R(0.01)*rng.normal();
-  } else if (TASK == TASK_CHEETAH || TASK == TASK_HUMANOID) {
+  } else if (TASK == TASK_CHEETAH || TASK == TASK_HUMANOID ||
+             TASK == TASK_WALKER || TASK == TASK_PENDULUM) {
     DMC_UNROLL
     for (int j = 0; j < NJNT; j++) {
       const int qa = jnt_qposadr[j];
       if (jnt_limited[j] && (jnt_type[j] == JNT_HINGE || jnt_type[j] == JNT_SLIDE)) {
         const real lo = R(jnt_range[2*j]), hi = R(jnt_range[2*j + 1]);
         qpos[qa] = lo + (hi - lo)*rng.uniform();
-      } else if (TASK == TASK_HUMANOID && !jnt_limited[j]) {
+      } else if (TASK != TASK_CHEETAH && !jnt_limited[j]) {
         if (jnt_type[j] == JNT_HINGE) {
           qpos[qa] = R(-3.141592653589793) + R(6.283185307179586)*rng.uniform();
         } else if (jnt_type[j] == JNT_FREE) {
@@ -1723,5 +1841,5 @@ dmc_init_episode(DmcArgs a) {
 // self-description read by dmc_api.cpp through hipModuleGetGlobal
 extern "C" __device__ const int dmc_info[16] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
-    (GLB_ROWS*RW + GLB_CONS*CW > 0 ? GLB_ROWS*RW + GLB_CONS*CW : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
+    (WS_WORDS > 0 ? WS_WORDS : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
     INTEGRATOR, NPAIR, 0, 0};

@@ -8,6 +8,7 @@ from dm_control_amd.mjcf import model as mdl
 from dm_control_amd.rl import control
 from dm_control_amd.suite import base
 from dm_control_amd.suite import common
+from dm_control_amd.suite.randomizers import randomize_limited_and_rotational_joints
 from dm_control_amd.utils import containers
 
 _DEFAULT_TIME_LIMIT = 25
@@ -80,26 +81,6 @@ class Physics(engine.Physics):
   def extremities(self):
     nq = self.model.nq
     return self.fused_observation()[..., nq - 7 + 1:nq - 7 + 13]
-
-
-def randomize_limited_and_rotational_joints(model, qpos, random):
-  """suite/utils/randomizers.py:35-86 on a plain qpos vector."""
-  for j in range(model.njnt):
-    jtype = model.jnt_type[j]
-    a = model.jnt_qposadr[j]
-    lo, hi = model.jnt_range[j]
-    if model.jnt_limited[j]:
-      if jtype in (mdl.JNT_HINGE, mdl.JNT_SLIDE):
-        qpos[a] = random.uniform(lo, hi)
-    else:
-      if jtype == mdl.JNT_HINGE:
-        qpos[a] = random.uniform(-np.pi, np.pi)
-      elif jtype == mdl.JNT_BALL:
-        quat = random.randn(4)
-        qpos[a:a + 4] = quat/np.linalg.norm(quat)
-      elif jtype == mdl.JNT_FREE:
-        quat = random.rand(4)
-        qpos[a + 3:a + 7] = quat/np.linalg.norm(quat)
 
 
 class Humanoid(base.Task):

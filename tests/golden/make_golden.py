@@ -120,9 +120,10 @@ def rewards_golden():
 
 
 def tasks_golden():
-  from dm_control.suite import cartpole, cheetah, humanoid
+  from dm_control.suite import cartpole, cheetah, humanoid, pendulum, walker
   rs = np.random.RandomState(1)
-  out = {'cartpole': [], 'cheetah': [], 'humanoid': []}
+  out = {'cartpole': [], 'cheetah': [], 'humanoid': [], 'walker': [],
+         'pendulum': []}
 
   for _ in range(24):
     x, cos, ctrl = rs.uniform(-2, 2), rs.uniform(-1, 1), rs.uniform(-1.5, 1.5)
@@ -172,6 +173,27 @@ def tasks_golden():
       t = humanoid.Humanoid(move_speed=speed, pure_state=False, random=0)
       rec['reward_speed_%d' % speed] = float(t.get_reward(P()))
     out['humanoid'].append(rec)
+
+  for _ in range(32):
+    height, zz, vel = rs.uniform(0.2, 1.6), rs.uniform(-1, 1), rs.uniform(-2, 10)
+
+    class P(walker.Physics):
+      def torso_height(self): return height
+      def torso_upright(self): return zz
+      def horizontal_velocity(self): return vel
+    rec = dict(torso_height=height, torso_upright=zz, horizontal_velocity=vel)
+    for speed in (0, 1, 8):
+      t = walker.PlanarWalker(move_speed=speed, random=0)
+      rec['reward_speed_%d' % speed] = float(t.get_reward(P()))
+    out['walker'].append(rec)
+
+  for _ in range(16):
+    zz = rs.uniform(0.95, 1.0) if rs.rand() < 0.5 else rs.uniform(-1, 1)
+
+    class P(pendulum.Physics):
+      def pole_vertical(self): return zz
+    out['pendulum'].append(dict(
+        pole_vertical=zz, reward=float(pendulum.SwingUp(random=0).get_reward(P()))))
   return out
 
 

@@ -10,9 +10,11 @@ from dm_control_amd.mjcf import compiler
 MODELS_DIR = os.path.join(os.path.dirname(os.path.dirname(
     os.path.abspath(__file__))), 'dm_control_amd', 'suite', 'models')
 TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
-         'humanoid': codegen.TASK_HUMANOID}
+         'humanoid': codegen.TASK_HUMANOID, 'walker': codegen.TASK_WALKER,
+         'pendulum': codegen.TASK_PENDULUM}
 # build mode per suite model (humanoid: see suite/humanoid.py)
-MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'unrolled'}
+MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'unrolled',
+         'walker': 'auto', 'pendulum': 'auto'}
 
 
 def load_model(name):
@@ -34,6 +36,16 @@ def initial_states(model, name, nenv, seed):
     qpos[:, lim] = rs.uniform(lo, hi, (nenv, lim.sum()))
     qpos[:, 1] = rs.uniform(-0.1, 0.3, nenv)
     qpos[:, 2] = rs.uniform(-0.5, 0.5, nenv)
+    qvel[:] = 0.5*rs.randn(nenv, model.nv)
+  elif name == 'pendulum':
+    qpos[:, 0] = rs.uniform(-np.pi, np.pi, nenv)
+    qvel[:] = rs.randn(nenv, 1)
+  elif name == 'walker':
+    lim = model.jnt_limited.astype(bool)
+    lo, hi = model.jnt_range[lim].T
+    qpos[:, lim] = rs.uniform(0.6*lo, 0.6*hi, (nenv, lim.sum()))
+    qpos[:, 0] = rs.uniform(-0.35, 0.05, nenv)    # rootz: feet near/into the floor
+    qpos[:, 2] = rs.uniform(-0.4, 0.4, nenv)
     qvel[:] = 0.5*rs.randn(nenv, model.nv)
   elif name == 'humanoid':
     for j in range(model.njnt):

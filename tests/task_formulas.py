@@ -52,3 +52,23 @@ def humanoid_reward(head_height, torso_upright, ctrl, com_velocity, move_speed):
                            sigmoid='linear')
   move = (5*move + 1)/6
   return small_control*stand_reward*move
+
+
+def walker_reward(torso_height, torso_upright, horizontal_velocity, move_speed):
+  """suite/walker.py:144-160."""
+  standing = rewards.tolerance(torso_height, bounds=(1.2, float('inf')),
+                               margin=1.2/2)
+  upright = (1 + torso_upright)/2
+  stand_reward = (3*standing + upright)/4
+  if move_speed == 0:
+    return stand_reward
+  move = rewards.tolerance(horizontal_velocity,
+                           bounds=(move_speed, float('inf')),
+                           margin=move_speed/2, value_at_margin=0.5,
+                           sigmoid='linear')
+  return stand_reward*(5*move + 1)/6
+
+
+def pendulum_reward(pole_vertical):
+  """suite/pendulum.py:119-120."""
+  return rewards.tolerance(pole_vertical, (np.cos(np.deg2rad(8)), 1))

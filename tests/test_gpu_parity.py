@@ -94,14 +94,16 @@ def _teacher_forced(name, precision, nenv, steps, nsub):
 
 
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
-                                       ('humanoid', 5)])
+                                       ('humanoid', 5), ('walker', 10),
+                                       ('pendulum', 1)])
 def test_fp64_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f64', nenv=64, steps=12, nsub=nsub)
   assert e.max() <= 1e-9, e.max()
 
 
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
-                                       ('humanoid', 5)])
+                                       ('humanoid', 5), ('walker', 10),
+                                       ('pendulum', 1)])
 def test_fp32_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f32', nenv=128, steps=12, nsub=nsub)
   assert np.median(e) <= 2e-6, np.median(e)
@@ -244,7 +246,9 @@ def test_fused_task_outputs_match_reference_formulas():
   for domain, task, nenv in (('cartpole', 'swingup', 64),
                              ('cartpole', 'balance_sparse', 64),
                              ('humanoid', 'walk', 32),
-                             ('humanoid', 'stand', 32)):
+                             ('humanoid', 'stand', 32),
+                             ('walker', 'run', 32), ('walker', 'stand', 32),
+                             ('pendulum', 'swingup', 64)):
     env = suite.load(domain, task, task_kwargs={'random': 4},
                      environment_kwargs={'batch_size': nenv})
     physics = env.physics
@@ -270,6 +274,21 @@ def test_fused_task_outputs_match_reference_formulas():
         np.testing.assert_allclose(ts.observation['position'][i],
                                    [qpos[i, 0], xmat[i, 2, 8], xmat[i, 2, 2]],
                                    atol=1e-6)
+      elif domain == 'walker':
+        m = physics.model
+        torso = m.name2id('torso', 'body')
+        want = task_formulas.walker_reward(
+            xpos[i, torso, 2], xmat[i, torso, 8],
+            np.asarray(physics.data.sensordata)[i, 0],
+            {'run': 8, 'stand': 0}[task])
+        np.testing.assert_allclose(ts.observation['orientations'][i],
+                                   xmat[i, 1:][:, [0, 2]].ravel(), atol=1e-6)
+        np.testing.assert_allclose(ts.observation['height'][i],
+                                   xpos[i, torso, 2])
+      elif domain == 'pendulum':
+        want = task_formulas.pendulum_reward(xmat[i, 1, 8])
+        np.testing.assert_allclose(ts.observation['orientation'][i],
+                                   [xmat[i, 1, 8], xmat[i, 1, 2]], atol=1e-6)
       else:
         m = physics.model
         com = np.asarray(physics.data.sensordata)[i, :3]

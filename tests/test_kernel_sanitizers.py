@@ -26,7 +26,7 @@ SHIM = os.path.join(ROOT, 'tests', 'host_shim')
 KERNEL = os.path.join(ROOT, 'dm_control_amd', 'csrc', 'dmc_kernels.hip')
 
 
-def _build(model, task, tmp_path, unroll):
+def _build(model, task, tmp_path, unroll, extra=()):
   header = tmp_path/'model.h'
   text = codegen.generate_header(model, task, unroll=unroll)
   header.write_text(text.replace('static __device__ constexpr',
@@ -34,7 +34,7 @@ def _build(model, task, tmp_path, unroll):
   exe = tmp_path/'harness'
   cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined',
          '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer',
-         '-DDMC_REAL_IS_DOUBLE', '-DDMC_LDS_BUDGET=16384',
+         '-DDMC_REAL_IS_DOUBLE', '-DDMC_LDS_BUDGET=16384'] + list(extra) + [
          '-DDMC_MODEL_HEADER="%s"' % header,
          '-DDMC_KERNEL_SOURCE="%s"' % KERNEL,
          '-I', os.path.join(ROOT, 'dm_control_amd', 'csrc'), '-I', SHIM,
@@ -60,9 +60,11 @@ def _run(exe, steps, qpos, qvel):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize('name,unroll', [('cheetah', True), ('cheetah', False),
-                                         ('primitives', True)])
-def test_kernel_source_is_clean_and_matches_oracle(name, unroll, tmp_path):
+@pytest.mark.parametrize('name,unroll,extra', [
+    ('cheetah', True, ()), ('cheetah', False, ()), ('primitives', True, ()),
+    ('primitives', True, ('-DDMC_BIGMAT=1',)),      # M / Hessian in memory
+    ('cheetah', True, ('-DDMC_BIGMAT=1', '-DDMC_LDS_BUDGET=65536'))])   # LDS matrix
+def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path):
   if name == 'primitives':
     model, task = compiler.from_xml_string(kat_models.PRIMITIVES), 0
     qpos, qvel = model.qpos0.copy(), np.zeros(model.nv)
@@ -73,7 +75,7 @@ def test_kernel_source_is_clean_and_matches_oracle(name, unroll, tmp_path):
     q, v = helpers.initial_states(model, name, 4, seed=7)
     qpos, qvel = q[1], v[1]
     steps = 25
-  exe = _build(model, task, tmp_path, unroll)
+  exe = _build(model, task, tmp_path, unroll, extra)
   rows = _run(exe, steps, qpos, qvel)
   assert len(rows) == steps
   d = oracle.OracleData(oracle.OracleModel(model))
