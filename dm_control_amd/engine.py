@@ -184,6 +184,12 @@ class _Data:
     self._p._batch.set_state(time=np.full(n, value, np.float64))
 
   @property
+  def timer(self):
+    """[[cumulative step seconds, step calls]] (cf. mjData.timer[0])."""
+    return np.array([[self._p._profile_seconds, self._p._profile_calls]],
+                    dtype=np.float64)
+
+  @property
   def ncon(self):
     """Contacts of the most recent collision pass (after `forward`)."""
     s = self._p._batch.read(wrapper.FIELD_STATS)[0]
@@ -252,6 +258,9 @@ class Physics(_control.Physics):
     self._pending_ctrl = None
     self._dirty = True
     self._aux_on = False
+    self._profiling = False
+    self._profile_seconds = 0.0
+    self._profile_calls = 0
     self._build_mode = build_mode or self._BUILD_MODE
     path = build.build_model(model, self._task_id, precision, ncon_max,
                              mode=self._build_mode)
@@ -298,6 +307,10 @@ class Physics(_control.Physics):
     finally:
       self._warnings_cause_exception = prev
 
+  def enable_profiling(self):
+    """Times every step launch with HIP events (engine.py:137-139)."""
+    self._profiling = True
+
   def set_control(self, control):
     """Stores the control applied by subsequent steps (engine.py:141-147)."""
     c = np.asarray(control, dtype=np.float64)
@@ -315,10 +328,16 @@ class Physics(_control.Physics):
   def step(self, n_sub_steps=1, outputs=True, check=True):
     """`n_sub_steps` x (mj_step2|mj_step + mj_step1), one kernel launch."""
     ctrl = self._pending_ctrl
+    if self._profiling:
+      self._batch.timer_start()
     if isinstance(ctrl, tuple):
       self._batch.step_device(ctrl[1], ctrl[2], ctrl[3], n_sub_steps, outputs)
     else:
       self._batch.step_host(ctrl, n_sub_steps, outputs)
+    if self._profiling:
+      ms, _ = self._batch.timer_stop()
+      self._profile_seconds += ms*1e-3
+      self._profile_calls += n_sub_steps
     self._pending_ctrl = None   # ctrl now lives in data.ctrl on the device
     self._dirty = not outputs
     if check:

@@ -1,0 +1,133 @@
+"""Suite-wide property tests on the GPU (strategy of suite/suite_test.py:68-288)
+and the suite wrappers (suite/wrappers/*_test.py)."""
+
+import collections
+
+import numpy as np
+import pytest
+
+from dm_control_amd import _dm_env as dm_env
+from dm_control_amd import suite
+from dm_control_amd.suite.wrappers import action_noise
+from dm_control_amd.suite.wrappers import action_scale
+from dm_control_amd.suite.wrappers import step_profiling
+
+pytestmark = pytest.mark.gpu
+
+_STEPS = 60
+
+
+def _uniform_action(spec, rs, batch):
+  shape = spec.shape if batch is None else (batch,) + spec.shape
+  return rs.uniform(spec.minimum, spec.maximum, shape)
+
+
+@pytest.mark.parametrize('domain,task', suite.ALL_TASKS)
+@pytest.mark.parametrize('batch', [None, 3])
+def test_task_properties(domain, task, batch):
+  """obs match the spec and stay finite (:149-167), rewards in [0, 1]
+  (:89-94), observations do not alias across steps (:237-247), no observation
+  element is constant (:249-278), same seed + actions => same bits (:169-185),
+  a new episode starts elsewhere (:280-288)."""
+  def make(seed):
+    kw = {} if batch is None else {'batch_size': batch}
+    return suite.load(domain, task, task_kwargs={'random': seed},
+                      environment_kwargs=kw)
+  env = make(42)
+  spec = env.action_spec()
+  obs_spec = env.observation_spec()
+  rs = np.random.RandomState(0)
+  actions = [_uniform_action(spec, rs, batch) for _ in range(_STEPS)]
+  first = env.reset()
+  assert first.first()
+  trace = [first]
+  for a in actions:
+    ts = env.step(a)
+    trace.append(ts)
+    assert not ts.first()
+    r = np.asarray(ts.reward)
+    assert np.all((r >= 0) & (r <= 1)), r
+    assert r.shape == (() if batch is None else (batch,))
+    for key, value in ts.observation.items():
+      value = np.asarray(value)
+      assert value.shape == obs_spec[key].shape
+      assert np.all(np.isfinite(value)), key
+  assert isinstance(trace[1].observation, collections.OrderedDict)
+  for key in first.observation:
+    a, b = trace[3].observation[key], trace[4].observation[key]
+    assert not np.shares_memory(a, b)
+    series = np.array([np.ravel(t.observation[key]) for t in trace[1:]])
+    assert np.all(series.std(axis=0) > 0), key          # nothing stays constant
+  env.physics.free()
+  env2 = make(42)
+  ts2 = env2.reset()
+  for a in actions:
+    ts2 = env2.step(a)
+  for key in ts2.observation:
+    np.testing.assert_array_equal(ts2.observation[key],
+                                  trace[-1].observation[key])
+  np.testing.assert_array_equal(ts2.reward, trace[-1].reward)
+  again = env2.reset()
+  assert any(not np.array_equal(again.observation[k], first.observation[k])
+             for k in first.observation)
+  env2.physics.free()
+
+
+def test_action_scale_wrapper():
+  env = suite.load('cheetah', 'run', task_kwargs={'random': 1},
+                   environment_kwargs={'batch_size': 4})
+  ref = suite.load('cheetah', 'run', task_kwargs={'random': 1},
+                   environment_kwargs={'batch_size': 4})
+  wrapped = action_scale.Wrapper(env, minimum=0.0, maximum=10.0)
+  spec = wrapped.action_spec()
+  assert spec.minimum.max() == 0 and spec.maximum.min() == 10
+  wrapped.reset()
+  ref.reset()
+  rs = np.random.RandomState(0)
+  for _ in range(3):
+    a = rs.uniform(0, 10, (4, 6))
+    ts = wrapped.step(a)
+    ts_ref = ref.step(a/5.0 - 1.0)
+  np.testing.assert_allclose(ts.observation['position'],
+                             ts_ref.observation['position'], atol=1e-6)
+  with pytest.raises(ValueError):
+    action_scale.Wrapper(env, minimum=-np.inf, maximum=1)
+  with pytest.raises(ValueError):
+    action_scale.Wrapper(env, minimum=np.zeros(5), maximum=np.ones(5))
+  env.physics.free()
+  ref.physics.free()
+
+
+def test_action_noise_wrapper():
+  env = suite.load('cartpole', 'swingup', task_kwargs={'random': 7})
+  clean = suite.load('cartpole', 'swingup', task_kwargs={'random': 7})
+  noisy = action_noise.Wrapper(env, scale=0.05)
+  noisy.reset()
+  clean.reset()
+  for _ in range(5):
+    a = noisy.step(np.array([0.5]))
+    b = clean.step(np.array([0.5]))
+  assert not np.array_equal(a.observation['velocity'], b.observation['velocity'])
+  # noise is clipped to the action bounds: ctrl stays within [-1, 1]
+  noisy.step(np.array([1.0]))
+  assert abs(np.asarray(env.physics.data.ctrl)[0]) <= 1.0
+  env.physics.free()
+  clean.physics.free()
+
+
+def test_step_profiling_wrapper():
+  env = suite.load('cheetah', 'run', task_kwargs={'random': 1},
+                   environment_kwargs={'batch_size': 8})
+  wrapped = step_profiling.Wrapper(env)
+  assert wrapped.observation_spec()['step_timing'].shape == (2,)
+  ts = wrapped.reset()
+  t0 = ts.observation['step_timing'].copy()
+  assert t0[1] >= 200            # the 200 settle steps of the reset were timed
+  for _ in range(3):
+    ts = wrapped.step(np.zeros((8, 6)))
+  t1 = ts.observation['step_timing']
+  assert t1[1] == t0[1] + 3 and t1[0] > t0[0]
+  dm_env.specs.Array((2,), np.double).validate(t1)
+  with pytest.raises(ValueError):
+    step_profiling.Wrapper(env, observation_key='position')
+  env.physics.free()
