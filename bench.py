@@ -140,7 +140,9 @@ def main():
   if world != args.gpus:
     if world == 1 and args.gpus > 1:
       raise SystemExit('launch with torch.distributed.run for --gpus > 1')
-  distributed = world > 1
+  # under torchrun (RANK set) the RCCL path is taken even for one rank, so the
+  # process-group / all-gather code is exercised on a single-GPU box as well
+  distributed = world > 1 or 'RANK' in os.environ
   if distributed:
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')

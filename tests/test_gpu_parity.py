@@ -476,3 +476,59 @@ def test_vec_env_numpy_and_torch_modes():
   np.testing.assert_array_equal(obs.cpu().numpy().astype(np.float64), robs)
   tenv.close()
   ref.close()
+
+
+@pytest.mark.parametrize('nenv', [1, 63, 65, 1000])
+def test_ragged_batch_sizes_match_full_batches(nenv):
+  """Partial last workgroup (the coalesced observation store and the early
+  exit of surplus lanes): env i of a ragged batch == env i of a 1024 batch."""
+  model = helpers.load_model('cheetah')
+  qpos, qvel = helpers.initial_states(model, 'cheetah', 1024, seed=5)
+  rs = np.random.RandomState(3)
+  ctrl = rs.uniform(-1, 1, (6, 1024, model.nu))
+  outs = []
+  for n in (1024, nenv):
+    hm, hb = _device_batch(model, codegen.TASK_CHEETAH, 'f32', n)
+    hb.set_state(qpos[:n].T, qvel[:n].T)
+    for t in range(6):
+      hb.step_host(ctrl[t, :n], 1)
+    outs.append((hb.read(W.FIELD_QPOS)[:, :nenv], hb.read(W.FIELD_OBS)[:nenv],
+                 hb.read(W.FIELD_REWARD)[:nenv], hb.read(W.FIELD_RETURN)[:nenv]))
+    hb.free()
+  for a, b in zip(*outs):
+    np.testing.assert_array_equal(a, b)
+
+
+def test_soak_full_episode_with_reset_cheetah_8192():
+  """1000 control steps + the automatic reset at BASELINE size: no warnings,
+  finite state, rewards in range, returns accumulated in-kernel equal the
+  sum of step rewards, and the next episode starts from a settled pose."""
+  import torch
+  from dm_control_amd import vec_env
+  n = 8192
+  env = vec_env.VecEnv('cheetah', 'run', n, seed=11, torch_io=True)
+  env.reset()
+  gen = torch.Generator(device='cuda').manual_seed(1)
+  total = torch.zeros(n, device='cuda')
+  acts = [torch.rand(n, 6, device='cuda', generator=gen)*2 - 1 for _ in range(32)]
+  batch = env.environment.physics.batch
+  for t in range(1000):
+    obs, rew, done, info = env.step(acts[t % 32])
+    total += rew
+    if t == 998:
+      ret = torch.from_numpy(batch.read(W.FIELD_RETURN)).cuda() + 0
+    if t < 999:
+      assert not bool(done[0])
+  assert bool(done.all()) and 'terminal_observation' in info
+  torch.cuda.synchronize()
+  assert not batch.read(W.FIELD_WARN).any()
+  assert torch.isfinite(obs).all() and torch.isfinite(total).all()
+  assert float(total.min()) >= 0 and float(total.max()) <= 1000
+  # in-kernel episode return after 999 steps == host-side sum of those rewards
+  np.testing.assert_allclose(ret.cpu().numpy(), (total - rew).cpu().numpy(),
+                             rtol=1e-4, atol=1e-3)
+  # after the auto-reset: time 0, return 0, cheetah resting (200 settle steps)
+  assert not batch.read(W.FIELD_TIME).any()
+  assert not batch.read(W.FIELD_RETURN).any()
+  assert np.abs(batch.read(W.FIELD_QVEL)).max() < 8.0
+  env.close()
