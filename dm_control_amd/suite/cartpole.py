@@ -1,7 +1,5 @@
 """Cartpole domain (cf. /root/reference/dm_control/suite/cartpole.py)."""
 
-import xml.etree.ElementTree as ET
-
 import numpy as np
 
 from dm_control_amd import codegen
@@ -69,18 +67,7 @@ def three_poles(time_limit=_DEFAULT_TIME_LIMIT, random=None, num_poles=3,
 
 def _make_model(n_poles):
   """Cart with a chain of `n_poles` poles (cartpole.py:105-128)."""
-  xml_string = common.read_model('cartpole.xml')
-  if n_poles == 1:
-    return xml_string
-  mjcf = ET.fromstring(xml_string)
-  parent = mjcf.find('./worldbody/body/body')
-  for pole_index in range(2, n_poles + 1):
-    child = ET.SubElement(parent, 'body', name='pole_{}'.format(pole_index),
-                          pos='0 0 1', childclass='pole')
-    ET.SubElement(child, 'joint', name='hinge_{}'.format(pole_index))
-    ET.SubElement(child, 'geom', name='pole_{}'.format(pole_index))
-    parent = child
-  return ET.tostring(mjcf, encoding='unicode')
+  return common.read_model('cartpole.xml', num_poles=n_poles)
 
 
 class Physics(engine.Physics):

@@ -1,8 +1,6 @@
 """Model files of the suite domains (cf. suite/common/__init__.py:22-34)."""
 
-import os
-
-_MODELS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'models')
+import importlib
 
 # The reference ships rendering-only includes (materials/skybox/visual); the
 # in-tree models are physics-only, so there are no assets to pass along.
@@ -15,10 +13,15 @@ PHYSICS_KWARGS = ('batch_size', 'device', 'precision', 'ncon_max',
 TASK_KWARGS = ('device_init',)
 
 
-def read_model(model_filename):
-  """Returns the contents of a model XML file as a string."""
-  with open(os.path.join(_MODELS_DIR, model_filename), 'r') as f:
-    return f.read()
+def read_model(model_filename, **kwargs):
+  """Returns the MJCF of a domain as a string.
+
+  The reference reads `<domain>.xml` from disk; here the physics-only model is
+  generated from the parameter tables in `suite/models/<domain>.py`.
+  """
+  name = model_filename[:-4] if model_filename.endswith('.xml') else model_filename
+  module = importlib.import_module('dm_control_amd.suite.models.' + name)
+  return module.build(**kwargs)
 
 
 def split_kwargs(environment_kwargs):

@@ -7,8 +7,6 @@ import numpy as np
 from dm_control_amd import codegen
 from dm_control_amd.mjcf import compiler
 
-MODELS_DIR = os.path.join(os.path.dirname(os.path.dirname(
-    os.path.abspath(__file__))), 'dm_control_amd', 'suite', 'models')
 TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
          'humanoid': codegen.TASK_HUMANOID, 'walker': codegen.TASK_WALKER,
          'pendulum': codegen.TASK_PENDULUM}
@@ -17,8 +15,13 @@ MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'unrolled',
          'walker': 'auto', 'pendulum': 'auto'}
 
 
+def model_xml(name):
+  from dm_control_amd.suite import common
+  return common.read_model(name + '.xml')
+
+
 def load_model(name):
-  return compiler.from_xml_path(os.path.join(MODELS_DIR, name + '.xml'))
+  return compiler.from_xml_string(model_xml(name))
 
 
 def initial_states(model, name, nenv, seed):

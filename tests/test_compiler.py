@@ -16,10 +16,12 @@ from oracle import oracle
 REF_SUITE = '/root/reference/dm_control/suite'
 
 
-@pytest.mark.parametrize('name', ['cartpole', 'cheetah', 'humanoid'])
+@pytest.mark.parametrize('name', ['cartpole', 'cheetah', 'humanoid', 'walker',
+                                  'pendulum'])
 def test_in_tree_models_compile_like_the_reference_files(name):
-  """The physics-only in-tree MJCFs give the same compiled model as the
-  reference's files (which carry rendering includes, sites, extra sensors)."""
+  """The in-tree parameter tables (suite/models/*.py) give the same compiled
+  model, names and ordering included, as the reference's MJCF files (which also
+  carry rendering includes, sites and sensors no task on the path reads)."""
   path = os.path.join(REF_SUITE, name + '.xml')
   if not os.path.exists(path):
     pytest.skip('reference tree not present')
@@ -30,11 +32,13 @@ def test_in_tree_models_compile_like_the_reference_files(name):
   for field, _ in mdl.FIELDS:
     if field in skip:
       continue
-    if name == 'cartpole' and (field.startswith('geom_') or field in (
+    if name in ('cartpole', 'pendulum') and (field.startswith('geom_') or field in (
         'ngeom', 'body_geomnum', 'body_geomadr')):
       continue   # decorative floor/rails dropped; contacts are disabled
     np.testing.assert_array_equal(np.asarray(a.field(field)),
                                   np.asarray(b.field(field)), err_msg=field)
+  for kind in ('body', 'joint', 'actuator'):
+    assert a.names[kind] == b.names[kind]
 
 
 def test_sizes_of_the_three_target_models():

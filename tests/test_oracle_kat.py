@@ -121,7 +121,7 @@ def test_k6_reset_forward_dynamics_and_actuation_flag():
   # the box starts exactly touching the floor (4 corner contacts at dist 0)
   np.testing.assert_allclose(p.data.qacc_smooth[2], -9.81, atol=1e-12)
   cart = oracle.OraclePhysics.from_xml_string(
-      open(__import__('helpers').MODELS_DIR + '/cartpole.xml').read())
+      __import__('helpers').model_xml('cartpole'))
   cart.reset()
   cart.data.ctrl[0] = 1.
   cart.after_reset()
