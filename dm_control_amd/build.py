@@ -122,9 +122,25 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
   return _spills(proc.stdout)
 
 
+def lds_budget_for(nenv):
+  """LDS bytes per workgroup for the constraint-row / contact staging area.
+
+  The step kernel is bound by VALU issue of one wave per SIMD, so how many
+  workgroups fit on a CU decides the throughput once the batch exceeds one
+  wave per CU.  Measured on cheetah-run (M env-steps/s at 128 / 64 / 36-40 KB):
+  B = 8192: 102 / 101 / 85;  16384: 201 / 198 / 169;  32768: 217 / 374 / 319;
+  65536: 228 / 404 / 583;  262144: 248 / 456 / 657.
+  """
+  if nenv is None or nenv <= 16384:
+    return 128*1024         # 1 workgroup per CU, most rows in LDS
+  if nenv <= 32768:
+    return 64*1024          # 2 per CU
+  return 36*1024            # 4 per CU: one wave on every SIMD
+
+
 def build_model(model, task=codegen.TASK_NONE, precision='f32',
                 ncon_max=None, force=False, keep_temps=False, extra_flags=None,
-                mode='auto'):
+                mode='auto', lds_budget=None):
   """Generates the constants header for `model` and compiles its kernels.
 
   mode: "unrolled" (static indexing, per-lane state in registers), "rolled"
@@ -139,6 +155,8 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
   if extra_flags is None:
     # experiment hook: extra -D flags for ablation builds (never set in tests)
     extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
+  if lds_budget is not None and lds_budget != 128*1024:
+    extra_flags = tuple(extra_flags) + ('-DDMC_LDS_BUDGET=%d' % lds_budget,)
   os.makedirs(_BUILD, exist_ok=True)
 
   def path(unroll):

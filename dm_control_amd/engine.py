@@ -262,8 +262,9 @@ class Physics(_control.Physics):
     self._profile_seconds = 0.0
     self._profile_calls = 0
     self._build_mode = build_mode or self._BUILD_MODE
-    path = build.build_model(model, self._task_id, precision, ncon_max,
-                             mode=self._build_mode)
+    path = build.build_model(
+        model, self._task_id, precision, ncon_max, mode=self._build_mode,
+        lds_budget=build.lds_budget_for(self._batch_size))
     self._hip_model = wrapper.HipModel(path, device)
     self._batch = wrapper.HipBatch(self._hip_model, self._batch_size)
     self.data = _Data(self)

@@ -36,8 +36,9 @@ pytestmark = pytest.mark.gpu
 W = wrapper
 
 
-def _device_batch(model, task, precision, nenv, mode='auto'):
-  hm = W.HipModel(build.build_model(model, task, precision, mode=mode))
+def _device_batch(model, task, precision, nenv, mode='auto', lds_budget=None):
+  hm = W.HipModel(build.build_model(model, task, precision, mode=mode,
+                                    lds_budget=lds_budget))
   return hm, W.HipBatch(hm, nenv)
 
 
@@ -62,10 +63,10 @@ def _degenerate(d, model):
   return False
 
 
-def _teacher_forced(name, precision, nenv, steps, nsub):
+def _teacher_forced(name, precision, nenv, steps, nsub, lds_budget=None):
   model = helpers.load_model(name)
   hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv,
-                         helpers.MODES[name])
+                         helpers.MODES[name], lds_budget)
   qpos, qvel = helpers.initial_states(model, name, nenv, seed=7)
   om, datas = _oracle_envs(model, qpos, qvel)
   rs = np.random.RandomState(11)
@@ -109,6 +110,32 @@ def test_fp32_build_matches_oracle_per_step(name, nsub):
   assert np.median(e) <= 2e-6, np.median(e)
   assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
   assert e.max() <= 5e-3, e.max()
+
+
+@pytest.mark.parametrize('lds_budget', [64*1024, 36*1024])
+def test_high_occupancy_variants_match_oracle(lds_budget):
+  """The code objects `build.lds_budget_for` picks for batches > 16384 envs
+  (smaller LDS row store, more rows in the HBM overflow tier) give the same
+  step: fp32 cheetah per-step parity, and bit-identical to the default build."""
+  e = _teacher_forced('cheetah', 'f32', nenv=128, steps=12, nsub=1,
+                      lds_budget=lds_budget)
+  assert np.median(e) <= 2e-6, np.median(e)
+  assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
+  model = helpers.load_model('cheetah')
+  qpos, qvel = helpers.initial_states(model, 'cheetah', 256, seed=3)
+  ctrl = np.random.RandomState(5).uniform(-1, 1, (30, 256, model.nu))
+  out = []
+  for budget in (None, lds_budget):
+    hm, hb = _device_batch(model, helpers.TASKS['cheetah'], 'f32', 256,
+                           lds_budget=budget)
+    hb.set_state(qpos.T, qvel.T)
+    for t in range(30):
+      hb.step_host(ctrl[t], 1)
+    out.append((hb.read(W.FIELD_QPOS), hb.read(W.FIELD_QVEL)))
+  np.testing.assert_array_equal(out[0][0], out[1][0])
+  np.testing.assert_array_equal(out[0][1], out[1][1])
+  assert build.lds_budget_for(8192) > build.lds_budget_for(32768) > \
+      build.lds_budget_for(65536)
 
 
 def _free_run(name, precision, nenv, steps, nsub):
