@@ -63,8 +63,8 @@ def model_key(model, task, precision, ncon_max=None, extra_flags=(),
   h.update(('%d/%s/%r/%r/%s/%d' % (
       task, precision, ncon_max, tuple(extra_flags),
       os.environ.get('DMC_PRAGMA_UNROLL_THRESHOLD', ''), int(unroll))).encode())
-  for path in (src, os.path.join(_CSRC, 'dmc_args.h'),
-               codegen.__file__):
+  for path in (src, os.path.join(_CSRC, 'dmc_coop.hip'),
+               os.path.join(_CSRC, 'dmc_args.h'), codegen.__file__):
     with open(path, 'rb') as f:
       h.update(f.read())
   return h.hexdigest()[:20]
@@ -85,7 +85,7 @@ def _spills(remarks, kernel='dmc_step'):
 
 
 def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
-             keep_temps):
+             keep_temps, source='dmc_kernels.hip', kernel='dmc_step'):
   key = os.path.basename(out)[4:-6]
   header = os.path.join(_BUILD, 'model_%s.h' % key)
   with open(header, 'w') as f:
@@ -104,7 +104,7 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
              'DMC_PRAGMA_UNROLL_THRESHOLD', '10000000'), '-fno-slp-vectorize',
          '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast',
          '-DDMC_MODEL_HEADER="%s"' % header, '-I', _CSRC,
-         '-o', out + '.tmp', os.path.join(_CSRC, 'dmc_kernels.hip')]
+         '-o', out + '.tmp', os.path.join(_CSRC, source)]
   cmd[1:1] = list(extra_flags)
   if precision == 'f64':
     cmd.insert(1, '-DDMC_REAL_IS_DOUBLE')
@@ -119,7 +119,7 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
                        % proc.stdout[-4000:])
   if keep_temps:
     print(proc.stdout)
-  return _spills(proc.stdout)
+  return _spills(proc.stdout, kernel)
 
 
 def lds_budget_for(nenv):
@@ -140,24 +140,40 @@ def lds_budget_for(nenv):
 
 def build_model(model, task=codegen.TASK_NONE, precision='f32',
                 ncon_max=None, force=False, keep_temps=False, extra_flags=None,
-                mode='auto', lds_budget=None):
+                mode='auto', lds_budget=None, group=64):
   """Generates the constants header for `model` and compiles its kernels.
 
   mode: "unrolled" (static indexing, per-lane state in registers), "rolled"
   (generic loops, per-lane arrays in scratch) or "auto" (unrolled unless its
-  register spills exceed MAX_*_SPILLS).  Returns the path of the gfx950 code
+  register spills exceed MAX_*_SPILLS), or "coop": `group` lanes advance one
+  env together with its working set in LDS (csrc/dmc_coop.hip; the shape for
+  nv ~ 20+ models and for small shards).  Returns the path of the gfx950 code
   object; cached in-tree by content hash.
   """
   if precision not in ('f32', 'f64'):
     raise ValueError('precision must be "f32" or "f64"')
-  if mode not in ('auto', 'unrolled', 'rolled'):
-    raise ValueError('mode must be auto, unrolled or rolled')
+  if mode not in ('auto', 'unrolled', 'rolled', 'coop'):
+    raise ValueError('mode must be auto, unrolled, rolled or coop')
   if extra_flags is None:
     # experiment hook: extra -D flags for ablation builds (never set in tests)
     extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
   if lds_budget is not None and lds_budget != 128*1024:
     extra_flags = tuple(extra_flags) + ('-DDMC_LDS_BUDGET=%d' % lds_budget,)
   os.makedirs(_BUILD, exist_ok=True)
+  if mode == 'coop':
+    # several lanes per env (csrc/dmc_coop.hip): working set in LDS, generic
+    # loops; `lds_budget` does not apply (no row tiers)
+    flags = tuple(f for f in extra_flags if not f.startswith('-DDMC_LDS_BUDGET'))
+    if group not in (8, 16, 32, 64):
+      raise ValueError('group must be 8, 16, 32 or 64 lanes per env')
+    flags += ('-DDMC_GROUP=%d' % group,)
+    out = os.path.join(_BUILD, 'dmc_%s.hsaco' % model_key(
+        model, task, precision, ncon_max, flags, True))
+    if force or not os.path.exists(out):
+      _compile(model, task, precision, ncon_max, flags, True, out, keep_temps,
+               source='dmc_coop.hip')
+      os.replace(out + '.tmp', out)
+    return out
 
   def path(unroll):
     return os.path.join(_BUILD, 'dmc_%s.hsaco' % model_key(

@@ -339,6 +339,35 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   ti('body_chain', [v for c in chains for v in (c + [0]*maxchain)[:maxchain]])
   ti('dof_anc_len', [len(a) for a in ancs])
   ti('dof_anc', [v for a in ancs for v in (a + [0]*maxchain)[:maxchain]])
+  # tables of the several-lanes-per-env kernel (csrc/dmc_coop.hip): bodies
+  # grouped by tree depth (one lane per body, one pass per level), subtree sizes
+  # (bodies are in depth-first order, so a subtree is a contiguous index range
+  # and "accumulate into the parent" becomes a race-free range sum), the joint
+  # of every dof, contact rows per pair
+  level = [0]*m.nbody
+  for b in range(1, m.nbody):
+    level[b] = level[int(m.body_parentid[b])] + 1
+  nlevel = max(level) if m.nbody > 1 else 0
+  order = sorted(range(1, m.nbody), key=lambda b: (level[b], b))
+  level_adr = [sum(1 for b in order if level[b] <= lv) for lv in range(nlevel + 1)]
+  subtree_n = [1]*m.nbody
+  for b in range(m.nbody - 1, 0, -1):
+    subtree_n[int(m.body_parentid[b])] += subtree_n[b]
+  for b in range(1, m.nbody):
+    p = int(m.body_parentid[b])
+    if not p <= b < p + subtree_n[p] or p >= b:
+      raise UnsupportedModelError('bodies are not in depth-first order')
+  dof_jntid = [0]*m.nv
+  for j in range(m.njnt):
+    width = {mdl.JNT_FREE: 6, mdl.JNT_BALL: 3}.get(int(m.jnt_type[j]), 1)
+    for k in range(width):
+      dof_jntid[int(m.jnt_dofadr[j]) + k] = j
+  ci('NLEVEL', nlevel)
+  ti('level_adr', level_adr)
+  ti('level_body', order)
+  ti('body_subtree_n', subtree_n)
+  ti('dof_jntid', dof_jntid)
+  ti('pair_nrow', [1 if mx['dim'] == 1 else 2*(mx['dim'] - 1) for mx in mixed])
   w('}  // namespace dmc_model')
   return '\n'.join(out) + '\n'
 

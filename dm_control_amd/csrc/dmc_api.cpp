@@ -75,7 +75,9 @@ struct dmc_batch {
 
 namespace {
 
-int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args) {
+// `group` = lanes that advance one env together (1: one env per lane; the
+// several-lanes-per-env kernels of dmc_coop.hip report theirs in dmc_info)
+int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args, int group = 1) {
   size_t size = sizeof(DmcArgs);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args,
                     HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
@@ -87,7 +89,9 @@ int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args) {
     const int v = atoi(env);
     if (v == 16 || v == 32 || v == 64) block = (unsigned)v;
   }
-  const unsigned grid = (unsigned)((b->nenv + block - 1)/block);
+  if (group > 1) block = 64;
+  const unsigned per_block = block/(unsigned)(group > 1 ? group : 1);
+  const unsigned grid = (unsigned)((b->nenv + per_block - 1)/per_block);
   HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, b->stream,
                                 nullptr, config));
   return 0;
@@ -180,6 +184,7 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   i.nu = raw[4]; i.nbody = raw[5]; i.nobs = raw[6]; i.nsensordata = raw[7];
   i.ws_per_env = raw[8]; i.task = raw[9]; i.ncon_max = raw[10];
   i.nefc_max = raw[11]; i.integrator = raw[12]; i.npair = raw[13];
+  i.lanes_per_env = raw[14] > 0 && raw[14] < 64 ? 64/raw[14] : 1;
   *out = m;
   return 0;
 }
@@ -318,7 +323,7 @@ int dmc_batch_forward(dmc_batch* b, int count_contacts) {
   DmcArgs a;
   fill_args(b, a);
   a.flags = count_contacts ? DMC_FLAG_COUNT_CONTACTS : 0;
-  return launch(b, b->model->k_observe, a);
+  return launch(b, b->model->k_observe, a, b->model->info.lanes_per_env);
 }
 
 int dmc_batch_step(dmc_batch* b, const void* ctrl, long long stride_k,
@@ -354,7 +359,7 @@ int dmc_batch_step(dmc_batch* b, const void* ctrl, long long stride_k,
     a.ctrl_sk = stride_k;
     a.ctrl_se = stride_env;
   }
-  if (launch(b, b->model->k_step, a)) return -1;
+  if (launch(b, b->model->k_step, a, b->model->info.lanes_per_env)) return -1;
   if (b->timing) b->launches++;
   return 0;
 }

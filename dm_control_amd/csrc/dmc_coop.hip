@@ -1,0 +1,1416 @@
+// dmc_coop.hip -- the physics step with SEVERAL LANES PER ENVIRONMENT.
+//
+// csrc/dmc_kernels.hip gives every environment one lane and keeps its whole
+// working set in that lane's registers.  That is the right shape for the small
+// planar models (nv <= ~10), and the wrong one for the 27-dof humanoid: 378
+// mass-matrix entries + 378 Hessian entries + the tree state do not fit one
+// lane's register file, and a 1024-env shard (BASELINE configs[3]) is only 16
+// waves on a 1024-SIMD chip.  Here a GROUP of G lanes (G = 32: two envs per
+// wave) advances one environment together:
+//
+//   * the env's working set lives in LDS (one region per env, ~35 KB fp32 for
+//     the humanoid incl. all 149 constraint rows -- no HBM workspace at all);
+//   * tree passes run one lane per body, level by level; dof-indexed work
+//     (mass-matrix rows, Jacobian columns, Hessian rows) one lane per dof;
+//     row-indexed work (reference acceleration, line search sums) one lane per
+//     constraint row; the static geom-pair list is strided over the lanes and
+//     compacted with an ordered prefix sum, so contacts and rows come out in
+//     exactly the order of the one-lane kernel and the CPU oracle;
+//   * Cholesky factor / solves of the nv x nv matrices are cooperative: one
+//     lane per matrix row, one phase per column.
+//
+// Lanes of a group communicate through LDS between phases (`gsync`) and
+// through group-wide shuffles for reductions; groups never interact, so the
+// two envs of a wave may take different numbers of Newton iterations.
+//
+// Same entry points, argument block and outputs as dmc_kernels.hip; the host
+// only needs `dmc_info[14]` (envs per 64-lane workgroup) to size the grid.
+// Reference path replaced: see dmc_kernels.hip (Physics.step, mj_step*, task
+// observation/reward of dm_control.suite).
+
+#define DMC_COOP_BUILD 1
+#include "dmc_kernels.hip"
+
+#ifndef DMC_GROUP
+#define DMC_GROUP 64
+#endif
+constexpr int G = DMC_GROUP;            // lanes per environment
+constexpr int EPB = 64/G;               // environments per 64-lane workgroup
+static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group must divide a wave");
+constexpr int RNV = (NVX + G - 1)/G;    // lane rounds needed to cover the dofs
+
+constexpr int odd_(int x) { return x | 1; }
+constexpr int NQX = NQ > 0 ? NQ : 1;
+constexpr int NJX = NJNT > 0 ? NJNT : 1;
+constexpr int NGX = NGEOM > 0 ? NGEOM : 1;
+constexpr int NOBSX = NOBS > 0 ? NOBS : 1;
+constexpr int NVP = odd_(NVX);          // row stride of M and H (odd: lane = row is conflict-free)
+// constraint row record: J(nv), D, aref, Jaref, Jv, force
+enum { CR_D = NV, CR_AREF = NV + 1, CR_JAR = NV + 2, CR_JV = NV + 3, CR_F = NV + 4 };
+constexpr int CRW = odd_(NV + 5);
+// contact record: pos(3) normal(3) tangent hint(3) dist pair first-row
+enum { CC_DIST = 9, CC_PAIR = 10, CC_ROW = 11 };
+constexpr int CCW = 13;
+constexpr bool RK4 = INTEGRATOR != 0;
+
+// word offsets of the per-env LDS region
+namespace off {
+constexpr int QPOS = 0;
+constexpr int QVEL = QPOS + NQX;
+constexpr int CTRL = QVEL + NVX;
+constexpr int WARM = CTRL + NUX;
+constexpr int XPOS = WARM + NVX;
+constexpr int XQUAT = XPOS + NBODY*3;
+constexpr int XMAT = XQUAT + NBODY*4;
+constexpr int XIPOS = XMAT + NBODY*9;
+constexpr int SUBCOM = XIPOS + NBODY*3;
+constexpr int CDOF = SUBCOM + NBODY*3;
+constexpr int CVEL = CDOF + NVX*6;
+constexpr int MM = CVEL + NBODY*6;
+// tree temporaries that are dead once qfrc_smooth exists; the triangular
+// solves reuse their space as the transposition scratch HH
+constexpr int TMP0 = MM + NVX*NVP;
+constexpr int XIMAT = TMP0;
+constexpr int XANCHOR = XIMAT + NBODY*9;
+constexpr int XAXIS = XANCHOR + NJX*3;
+constexpr int CINERT = XAXIS + NJX*3;
+constexpr int CRB = CINERT + NBODY*10;
+constexpr int CDOFDOT = CRB + NBODY*10;
+constexpr int CACC = CDOFDOT + NVX*6;
+constexpr int CFRC = CACC + NBODY*6;
+constexpr int TMP1 = CFRC + NBODY*6;
+constexpr int HH = TMP0;
+constexpr int TMPEND = TMP1 - TMP0 > NVX*NVP ? TMP1 : TMP0 + NVX*NVP;
+constexpr int FS = TMPEND;              // qfrc_smooth
+constexpr int FC = FS + NVX;            // qfrc_constraint
+constexpr int QAS = FC + NVX;           // qacc_smooth
+constexpr int QACC = QAS + NVX;
+constexpr int MA = QACC + NVX;
+constexpr int MV = MA + NVX;
+constexpr int GRAD = MV + NVX;
+constexpr int SEARCH = GRAD + NVX;
+constexpr int GEOM = SEARCH + NVX;
+constexpr int CON = GEOM + NGX*12;
+constexpr int ROWS = CON + NCON_MAX*CCW;
+constexpr int SLV = ROWS + NEFC_MAX*CRW;
+constexpr int OBSV = SLV + NBODY*3;
+constexpr int Q0 = OBSV + NOBSX;        // RK4 stage storage
+constexpr int V0 = Q0 + (RK4 ? NQX : 0);
+constexpr int FV = V0 + (RK4 ? NVX : 0);
+constexpr int FA = FV + (RK4 ? 4*NVX : 0);
+constexpr int DV = FA + (RK4 ? 4*NVX : 0);
+constexpr int END = DV + (RK4 ? NVX : 0);
+}  // namespace off
+// region stride: groups that share a 32-lane LDS half start G banks apart
+constexpr int ENV_WORDS = ((off::END + 31)/32)*32 + (G % 32);
+static_assert((long long)ENV_WORDS*EPB*sizeof(real) <= 150*1024,
+              "the env working set does not fit in LDS; use the one-lane kernel");
+
+// ---------------------------------------------------------------------------
+// group primitives
+// ---------------------------------------------------------------------------
+#ifndef DMC_HOST_SHIM
+// LDS hand-over between phases.  The workgroup is one wave and the lanes of a
+// group run in lock step, so no hardware barrier is needed: what must be
+// prevented is the compiler moving LDS accesses across the phase boundary.
+DEV void gsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+DEV real gxor(real x, int m) { return __shfl_xor(x, m, G); }
+DEV int gxor(int x, int m) { return __shfl_xor(x, m, G); }
+DEV int gup(int x, int d) { return __shfl_up(x, d, G); }
+DEV int gget(int x, int src) { return __shfl(x, src, G); }
+DEV real gget(real x, int src) { return __shfl(x, src, G); }
+// value of `x` in lane `src` of the caller's group, `src` uniform over the
+// wave: v_readlane per group instead of a trip through the LDS crossbar
+DEV int gbcast_bits(int x, int src) {
+  if (G == 64) return __builtin_amdgcn_readlane(x, src);
+  if (G == 32) {
+    const int lo = __builtin_amdgcn_readlane(x, src);
+    const int hi = __builtin_amdgcn_readlane(x, src + 32);
+    return (threadIdx.x & 32) ? hi : lo;
+  }
+  return __shfl(x, src, G);
+}
+DEV int gbcast(int x, int src) { return gbcast_bits(x, src); }
+DEV float gbcast(float x, int src) {
+  return __int_as_float(gbcast_bits(__float_as_int(x), src));
+}
+DEV double gbcast(double x, int src) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)gbcast_bits((int)(unsigned)(b & 0xffffffffLL), src);
+  const unsigned hi = (unsigned)gbcast_bits((int)(unsigned)((unsigned long long)b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#endif
+// Group reductions.  Butterfly sums: every lane ends with the bitwise-identical
+// total (each stage adds the same two partial sums in both partner lanes), so
+// control flow that depends on them stays uniform inside the group.  On the
+// GPU the stages inside a 16-lane row are DPP moves (quad permutes and the two
+// row mirrors pair exactly the lanes an xor butterfly would pair once the
+// smaller blocks are uniform); only the row-to-row stage crosses through the
+// LDS crossbar.
+#ifndef DMC_HOST_SHIM
+template <int CTRL>
+DEV int dpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+template <int CTRL> DEV int dpp(int x) { return dpp_i<CTRL>(x); }
+template <int CTRL> DEV float dpp(float x) { return __int_as_float(dpp_i<CTRL>(__float_as_int(x))); }
+template <int CTRL> DEV double dpp(double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)dpp_i<CTRL>((int)(unsigned)(b & 0xffffffffLL));
+  const unsigned hi = (unsigned)dpp_i<CTRL>((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140,
+       DPP_SHR1 = 0x111, DPP_SHR2 = 0x112, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118 };
+template <class T>
+DEV T gsum_t(T x) {
+  if (G >= 16) {
+    x += dpp<DPP_XOR1>(x);
+    x += dpp<DPP_XOR2>(x);
+    x += dpp<DPP_HALF_MIRROR>(x);
+    x += dpp<DPP_MIRROR>(x);
+    if (G == 64) {   // four uniform row totals: add them in a fixed order
+      const T r0 = gbcast(x, 0), r1 = gbcast(x, 16), r2 = gbcast(x, 32), r3 = gbcast(x, 48);
+      x = (r0 + r1) + (r2 + r3);
+    } else {
+      for (int m = 16; m < G; m <<= 1) x += gxor(x, m);
+    }
+  } else {
+    for (int m = G/2; m > 0; m >>= 1) x += gxor(x, m);
+  }
+  return x;
+}
+// exclusive prefix sum in lane order + group total
+DEV int gscan(int x, int lane, int& total) {
+  int v = x;
+  if (G >= 16) {
+    v += dpp<DPP_SHR1>(v);      // bound_ctrl: lanes shifted in from outside the row read 0
+    v += dpp<DPP_SHR2>(v);
+    v += dpp<DPP_SHR4>(v);
+    v += dpp<DPP_SHR8>(v);
+    for (int r = 16; r < G; r += 16) {   // carry the running total into the next row
+      const int t = gbcast_bits(v, r - 1);
+      if (lane >= r && lane < r + 16) v += t;
+    }
+  } else {
+    for (int d = 1; d < G; d <<= 1) {
+      const int t = gup(v, d);
+      if (lane >= d) v += t;
+    }
+  }
+  total = gbcast_bits(v, G - 1);
+  return v - x;
+}
+#else
+template <class T>
+DEV T gsum_t(T x) {
+  for (int m = G/2; m > 0; m >>= 1) x += gxor(x, m);
+  return x;
+}
+DEV int gscan(int x, int lane, int& total) {
+  int v = x;
+  for (int d = 1; d < G; d <<= 1) {
+    const int t = gup(v, d);
+    if (lane >= d) v += t;
+  }
+  total = gget(v, G - 1);
+  return v - x;
+}
+#endif
+DEV real gsum(real x) { return gsum_t(x); }
+DEV int gsum(int x) { return gsum_t(x); }
+DEV bool gany(bool b) { return gsum(b ? 1 : 0) != 0; }
+
+// -DDMC_COOP_PROFILE: per-phase time (100 MHz ticks) of every env, summed over
+// the launch, written over the first words of the env's observation (experiments only)
+#ifdef DMC_COOP_PROFILE
+enum { PH_KIN, PH_COM, PH_CRB, PH_FACM, PH_VEL, PH_SMOOTH, PH_LIMIT, PH_DETECT, PH_CROWS,
+       PH_FINISH, PH_WARM, PH_HESS, PH_FACH, PH_SOLVE, PH_LS, PH_UPD, PH_EULER, PH_OBS, PH_N };
+#define PROF(k) do { const long long t_ = wall_clock64(); tprof[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PROF(k) do {} while (0)
+#endif
+
+// Model tables that the tree / row passes index with per-lane values (body,
+// joint and dof ids differ from lane to lane, so these cannot be scalar loads).
+// They are staged once per workgroup in LDS -- a dependent chain of three
+// global loads per tree level (level_body -> body_jntadr -> jnt_qposadr)
+// otherwise costs more than the arithmetic of the level.  Inside `Coop` the
+// table names below resolve to these LDS mirrors; integers are stored as reals
+// (all are < 2^24).
+#define COOP_TABLES(X) \
+  X(I, level_adr, NLEVEL + 1) X(I, level_body, NBODY > 1 ? NBODY - 1 : 1) \
+  X(I, body_parentid, NBODY) X(I, body_rootid, NBODY) X(I, body_jntnum, NBODY) \
+  X(I, body_jntadr, NBODY) X(I, body_subtree_n, NBODY) \
+  X(R, body_pos, 3*NBODY) X(R, body_quat, 4*NBODY) X(R, body_ipos, 3*NBODY) \
+  X(R, body_iquat, 4*NBODY) X(R, body_mass, NBODY) X(R, body_subtreemass, NBODY) \
+  X(R, body_inertia, 3*NBODY) \
+  X(I, jnt_type, NJX) X(I, jnt_qposadr, NJX) X(I, jnt_dofadr, NJX) X(I, jnt_bodyid, NJX) \
+  X(R, jnt_pos, 3*NJX) X(R, jnt_axis, 3*NJX) X(R, jnt_stiffness, NJX) \
+  X(R, jnt_range, 2*NJX) X(R, jnt_margin, NJX) \
+  X(R, qpos0, NQX) X(R, qpos_spring, NQX) \
+  X(I, dof_bodyid, NVX) X(I, dof_jntid, NVX) X(I, dof_anc_len, NVX) X(I, dof_anc, NVX*MAXCHAIN) \
+  X(R, dof_armature, NVX) X(R, dof_damping, NVX) X(R, dof_invweight0, NVX) \
+  X(I, geom_bodyid, NGX) X(R, geom_pos, 3*NGX) X(R, geom_quat, 4*NGX)
+namespace tb {
+enum : int {
+#define X(kind, name, n) name##_off, name##_last = name##_off + (n) - 1,
+  COOP_TABLES(X)
+#undef X
+  END
+};
+}  // namespace tb
+__shared__ real coop_tab[tb::END];
+template <int OFF> struct LdsTabI {
+  __device__ __forceinline__ int operator[](int i) const { return (int)coop_tab[OFF + i]; }
+};
+template <int OFF> struct LdsTabR {
+  __device__ __forceinline__ real operator[](int i) const { return coop_tab[OFF + i]; }
+};
+// every lane of the workgroup takes part (call before any lane leaves)
+DEV void stage_tables() {
+#define X(kind, name, n) \
+  for (int k = threadIdx.x; k < (n); k += 64) coop_tab[tb::name##_off + k] = (real)dmc_model::name[k];
+  COOP_TABLES(X)
+#undef X
+  __syncthreads();
+}
+
+struct EnvView {   // the fields task_outputs() reads, as LDS pointers
+  const real *qpos, *qvel, *ctrl, *xpos, *xmat, *subtree_linvel;
+};
+
+// ---------------------------------------------------------------------------
+// one environment, advanced by the G lanes of its group
+// ---------------------------------------------------------------------------
+struct Coop {
+  real* S;         // LDS region of this env
+  int l;           // lane within the group
+  real time;
+  unsigned warn;
+  int ncon, nefc, iters;
+#ifdef DMC_COOP_PROFILE
+  long long tprof[PH_N], tlast;
+#endif
+  // LDS mirrors shadow the namespace-scope tables inside the member functions
+#define X(kind, name, n) LdsTab##kind<tb::name##_off> name;
+  COOP_TABLES(X)
+#undef X
+
+  // ---- cooperative dense linear algebra -----------------------------------
+  // Lane (l + t*G) keeps row (l + t*G) of a symmetric NV x NV matrix in
+  // registers (`Rows`); all indices below are compile-time after unrolling and
+  // the pivot row reaches the other lanes through register broadcasts, so a
+  // factorisation is ~NV^2/2 broadcast+FMA pairs with no memory latency in the
+  // dependence chain.  (A first version kept the matrix in LDS and synchronised
+  // per column: 25 us per 27 x 27 factorisation, every inner step paying an LDS
+  // round trip.)
+  struct Rows { real a[RNV][NVX]; };
+
+  __device__ void rows_load(Rows& A, int src) const {
+    _Pragma("unroll")
+    for (int t = 0; t < RNV; t++) {
+      const int i = l + t*G;
+      _Pragma("unroll")
+      for (int k = 0; k < NV; k++) A.a[t][k] = i < NV ? S[src + i*NVP + k] : R(0);
+    }
+  }
+  // in place A = L L^T (right-looking); lane i ends with L[i][0..i-1] and
+  // 1/L[i][i] in a[i]; entries right of the diagonal are dead
+  __device__ int rows_chol(Rows& A) const {
+    int nbad = 0;
+    _Pragma("unroll")
+    for (int j = 0; j < NV; j++) {
+      real d = gbcast(A.a[j/G][j], j % G);
+      if (!(d >= DMC_MINVAL)) { d = DMC_MINVAL; nbad++; }
+      const real inv = rsqrt_(d);
+      real lij[RNV];
+      _Pragma("unroll")
+      for (int t = 0; t < RNV; t++) {
+        lij[t] = A.a[t][j]*inv;
+        A.a[t][j] = (l + t*G == j) ? inv : lij[t];
+      }
+      _Pragma("unroll")
+      for (int k = j + 1; k < NV; k++) {
+        const real lkj = gbcast(lij[k/G], k % G);
+        _Pragma("unroll")
+        for (int t = 0; t < RNV; t++) A.a[t][k] -= lij[t]*lkj;
+      }
+    }
+    return nbad;
+  }
+  // x = (L L^T)^-1 b, b/x held one entry per lane row.  The backward sweep
+  // needs column i of L in lane i: the factor is transposed through the LDS
+  // square at `scratch` (one write + one read per entry, all independent).
+  __device__ void rows_solve(const Rows& A, int scratch, real* b) {
+    _Pragma("unroll")
+    for (int t = 0; t < RNV; t++) {
+      const int i = l + t*G;
+      if (i < NV) {
+        _Pragma("unroll")
+        for (int k = 0; k < NV; k++) S[scratch + i*NVP + k] = A.a[t][k];
+      }
+    }
+    _Pragma("unroll")
+    for (int k = 0; k < NV; k++) {          // forward: L y = b
+      const real yk = gbcast(b[k/G]*A.a[k/G][k], k % G);
+      _Pragma("unroll")
+      for (int t = 0; t < RNV; t++) {
+        const int i = l + t*G;
+        b[t] = i == k ? yk : (i > k ? b[t] - A.a[t][k]*yk : b[t]);
+      }
+    }
+    gsync();
+    real lt[RNV][NVX];
+    _Pragma("unroll")
+    for (int t = 0; t < RNV; t++) {
+      const int i = l + t*G;
+      _Pragma("unroll")
+      for (int k = 0; k < NV; k++) lt[t][k] = i < NV ? S[scratch + k*NVP + i] : R(0);
+    }
+    _Pragma("unroll")
+    for (int k = NV - 1; k >= 0; k--) {     // backward: L^T x = y
+      const real xk = gbcast(b[k/G]*A.a[k/G][k], k % G);
+      _Pragma("unroll")
+      for (int t = 0; t < RNV; t++) {
+        const int i = l + t*G;
+        b[t] = i == k ? xk : (i < k ? b[t] - lt[t][k]*xk : b[t]);
+      }
+    }
+    gsync();   // `scratch` may be rewritten by the caller from here on
+  }
+  // y_i = sum_k M_ik x_k for this lane's rows (M stored full and symmetric)
+  __device__ real mrow_dot(int i, int x) const {
+    real s = 0;
+    _Pragma("unroll")
+    for (int k = 0; k < NV; k++) s += S[off::MM + i*NVP + k]*S[x + k];
+    return s;
+  }
+
+  // ---- position stage ------------------------------------------------------
+  __device__ void kin_body(int i) {
+    real xpos[3], xquat[4];
+    const int jadr = body_jntadr[i], jnum = body_jntnum[i];
+    if (jnum == 1 && jnt_type[jadr < 0 ? 0 : jadr] == JNT_FREE) {
+      const int qa = jnt_qposadr[jadr];
+      for (int k = 0; k < 3; k++) xpos[k] = S[off::QPOS + qa + k];
+      for (int k = 0; k < 4; k++) xquat[k] = S[off::QPOS + qa + 3 + k];
+      normalize4(xquat);
+      for (int k = 0; k < 3; k++) {
+        S[off::XANCHOR + 3*jadr + k] = xpos[k];
+        S[off::XAXIS + 3*jadr + k] = R(jnt_axis[3*jadr + k]);
+      }
+    } else {
+      const int pid = body_parentid[i];
+      real bp[3] = {R(body_pos[3*i]), R(body_pos[3*i + 1]), R(body_pos[3*i + 2])};
+      real bq[4] = {R(body_quat[4*i]), R(body_quat[4*i + 1]),
+                    R(body_quat[4*i + 2]), R(body_quat[4*i + 3])};
+      real pm[9], pq[4], v[3];
+      for (int k = 0; k < 9; k++) pm[k] = S[off::XMAT + 9*pid + k];
+      for (int k = 0; k < 4; k++) pq[k] = S[off::XQUAT + 4*pid + k];
+      mulmatvec3(v, pm, bp);
+      for (int k = 0; k < 3; k++) xpos[k] = S[off::XPOS + 3*pid + k] + v[k];
+      mulquat(xquat, pq, bq);
+      for (int j = 0; j < jnum; j++) {
+        const int jid = jadr + j, qa = jnt_qposadr[jid], jt = jnt_type[jid];
+        real jax[3] = {R(jnt_axis[3*jid]), R(jnt_axis[3*jid + 1]), R(jnt_axis[3*jid + 2])};
+        real jp[3] = {R(jnt_pos[3*jid]), R(jnt_pos[3*jid + 1]), R(jnt_pos[3*jid + 2])};
+        real anchor[3], axis[3];
+        rotvecquat(axis, jax, xquat);
+        rotvecquat(anchor, jp, xquat);
+        for (int k = 0; k < 3; k++) anchor[k] += xpos[k];
+        for (int k = 0; k < 3; k++) {
+          S[off::XANCHOR + 3*jid + k] = anchor[k];
+          S[off::XAXIS + 3*jid + k] = axis[k];
+        }
+        if (jt == JNT_SLIDE) {
+          const real q = S[off::QPOS + qa] - R(qpos0[qa]);
+          for (int k = 0; k < 3; k++) xpos[k] += axis[k]*q;
+        } else if (jt == JNT_HINGE || jt == JNT_BALL) {
+          real qloc[4], r[4], vec[3];
+          if (jt == JNT_BALL) {
+            for (int k = 0; k < 4; k++) qloc[k] = S[off::QPOS + qa + k];
+            normalize4(qloc);
+          } else {
+            axisangle2quat(qloc, jax, S[off::QPOS + qa] - R(qpos0[qa]));
+          }
+          mulquat(r, xquat, qloc);
+          for (int k = 0; k < 4; k++) xquat[k] = r[k];
+          rotvecquat(vec, jp, xquat);
+          for (int k = 0; k < 3; k++) xpos[k] = anchor[k] - vec[k];
+        }
+      }
+    }
+    normalize4(xquat);
+    real xm[9];
+    quat2mat(xm, xquat);
+    for (int k = 0; k < 3; k++) S[off::XPOS + 3*i + k] = xpos[k];
+    for (int k = 0; k < 4; k++) S[off::XQUAT + 4*i + k] = xquat[k];
+    for (int k = 0; k < 9; k++) S[off::XMAT + 9*i + k] = xm[k];
+    real ip[3] = {R(body_ipos[3*i]), R(body_ipos[3*i + 1]), R(body_ipos[3*i + 2])};
+    real iq[4] = {R(body_iquat[4*i]), R(body_iquat[4*i + 1]),
+                  R(body_iquat[4*i + 2]), R(body_iquat[4*i + 3])};
+    real v[3], q[4], im[9];
+    mulmatvec3(v, xm, ip);
+    for (int k = 0; k < 3; k++) S[off::XIPOS + 3*i + k] = xpos[k] + v[k];
+    mulquat(q, xquat, iq);
+    quat2mat(im, q);
+    for (int k = 0; k < 9; k++) S[off::XIMAT + 9*i + k] = im[k];
+  }
+
+  __device__ void kinematics() {
+    if (l == 0) {   // world body
+      for (int k = 0; k < 3; k++) { S[off::XPOS + k] = 0; S[off::XIPOS + k] = 0; }
+      S[off::XQUAT] = 1; S[off::XQUAT + 1] = S[off::XQUAT + 2] = S[off::XQUAT + 3] = 0;
+      for (int k = 0; k < 9; k++) {
+        const real v = (k == 0 || k == 4 || k == 8) ? R(1) : R(0);
+        S[off::XMAT + k] = v; S[off::XIMAT + k] = v;
+      }
+    }
+    gsync();
+    for (int lev = 0; lev < NLEVEL; lev++) {
+      for (int idx = level_adr[lev] + l; idx < level_adr[lev + 1]; idx += G)
+        kin_body(level_body[idx]);
+      gsync();
+    }
+  }
+
+  __device__ void com_pos() {
+    // subtree centre of mass: bodies are depth-first ordered, a subtree is the
+    // index range [i, i + body_subtree_n[i])
+    for (int i = l; i < NBODY; i += G) {
+      real acc[3] = {0, 0, 0};
+      const int n = body_subtree_n[i];
+      for (int j = i; j < i + n; j++) {
+        const real mass = R(body_mass[j]);
+        for (int k = 0; k < 3; k++) acc[k] += mass*S[off::XIPOS + 3*j + k];
+      }
+      if (body_subtreemass[i] < 1e-15) {
+        for (int k = 0; k < 3; k++) acc[k] = S[off::XIPOS + 3*i + k];
+      } else {
+        const real inv = R(1)/R(body_subtreemass[i]);
+        for (int k = 0; k < 3; k++) acc[k] *= inv;
+      }
+      for (int k = 0; k < 3; k++) S[off::SUBCOM + 3*i + k] = acc[k];
+    }
+    gsync();
+    for (int i = l; i < NBODY; i += G) {
+      real* res = S + off::CINERT + 10*i;
+      if (i == 0) { for (int k = 0; k < 10; k++) res[k] = 0; continue; }
+      const real* com = S + off::SUBCOM + 3*body_rootid[i];
+      const real* mat = S + off::XIMAT + 9*i;
+      real dif[3], t[9], m[9];
+      const real mass = R(body_mass[i]);
+      const real in0 = R(body_inertia[3*i]), in1 = R(body_inertia[3*i + 1]),
+                 in2 = R(body_inertia[3*i + 2]);
+      for (int k = 0; k < 9; k++) m[k] = mat[k];
+      for (int k = 0; k < 3; k++) dif[k] = S[off::XIPOS + 3*i + k] - com[k];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++)
+          t[3*a + b] = m[3*a]*in0*m[3*b] + m[3*a + 1]*in1*m[3*b + 1] +
+                       m[3*a + 2]*in2*m[3*b + 2];
+      res[0] = t[0] + mass*(dif[1]*dif[1] + dif[2]*dif[2]);
+      res[1] = t[4] + mass*(dif[0]*dif[0] + dif[2]*dif[2]);
+      res[2] = t[8] + mass*(dif[0]*dif[0] + dif[1]*dif[1]);
+      res[3] = t[1] - mass*dif[0]*dif[1];
+      res[4] = t[2] - mass*dif[0]*dif[2];
+      res[5] = t[5] - mass*dif[1]*dif[2];
+      res[6] = mass*dif[0]; res[7] = mass*dif[1]; res[8] = mass*dif[2];
+      res[9] = mass;
+    }
+    for (int j = l; j < NJNT; j += G) {
+      const int b = jnt_bodyid[j], da = jnt_dofadr[j], jt = jnt_type[j];
+      const real* com = S + off::SUBCOM + 3*body_rootid[b];
+      real offv[3];
+      for (int k = 0; k < 3; k++) offv[k] = com[k] - S[off::XANCHOR + 3*j + k];
+      real* cd = S + off::CDOF + 6*da;
+      if (jt == JNT_FREE || jt == JNT_BALL) {
+        if (jt == JNT_FREE) {
+          for (int k = 0; k < 18; k++) cd[k] = 0;
+          cd[3] = 1; cd[6 + 4] = 1; cd[12 + 5] = 1;
+          cd += 18;
+        }
+        for (int k = 0; k < 3; k++) {
+          real ax[3] = {S[off::XMAT + 9*b + k], S[off::XMAT + 9*b + 3 + k],
+                        S[off::XMAT + 9*b + 6 + k]};
+          real c[3];
+          cross3(c, ax, offv);
+          for (int d = 0; d < 3; d++) { cd[6*k + d] = ax[d]; cd[6*k + 3 + d] = c[d]; }
+        }
+      } else if (jt == JNT_SLIDE) {
+        for (int k = 0; k < 3; k++) { cd[k] = 0; cd[3 + k] = S[off::XAXIS + 3*j + k]; }
+      } else {
+        real ax[3], c[3];
+        for (int k = 0; k < 3; k++) ax[k] = S[off::XAXIS + 3*j + k];
+        cross3(c, ax, offv);
+        for (int k = 0; k < 3; k++) { cd[k] = ax[k]; cd[3 + k] = c[k]; }
+      }
+    }
+    gsync();
+  }
+
+  // composite inertias and the full symmetric mass matrix
+  __device__ void crb_matrix() {
+    for (int i = l; i < NBODY; i += G) {
+      real acc[10];
+      for (int k = 0; k < 10; k++) acc[k] = 0;
+      if (i > 0) {
+        const int n = body_subtree_n[i];
+        for (int j = i; j < i + n; j++)
+          for (int k = 0; k < 10; k++) acc[k] += S[off::CINERT + 10*j + k];
+      }
+      for (int k = 0; k < 10; k++) S[off::CRB + 10*i + k] = acc[k];
+    }
+    for (int k = l; k < NV*NVP; k += G) S[off::MM + k] = 0;
+    gsync();
+    for (int i = l; i < NV; i += G) {
+      real buf[6], cd[6], crb[10];
+      for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*i + k];
+      for (int k = 0; k < 10; k++) crb[k] = S[off::CRB + 10*dof_bodyid[i] + k];
+      mul_inert_vec(buf, crb, cd);
+      S[off::MM + i*NVP + i] = dot6(cd, buf) + R(dof_armature[i]);
+      const int na = dof_anc_len[i];
+      for (int a = 0; a < na; a++) {
+        const int j = dof_anc[i*MAXCHAIN + a];
+        real cj[6];
+        for (int k = 0; k < 6; k++) cj[k] = S[off::CDOF + 6*j + k];
+        const real v = dot6(cj, buf);
+        S[off::MM + i*NVP + j] = v;
+        S[off::MM + j*NVP + i] = v;
+      }
+    }
+    gsync();
+    PROF(PH_CRB);
+  }
+
+  // ---- velocity stage --------------------------------------------------------
+  // body velocity, cdof_dot and the bias acceleration, one tree level per phase
+  __device__ void vel_body(int i) {
+    const int pid = body_parentid[i];
+    real cvel[6], cacc[6];
+    for (int k = 0; k < 6; k++) {
+      cvel[k] = S[off::CVEL + 6*pid + k];
+      cacc[k] = S[off::CACC + 6*pid + k];
+    }
+    const int jadr = body_jntadr[i], jnum = body_jntnum[i];
+    for (int j = 0; j < jnum; j++) {
+      const int jid = jadr + j, jt = jnt_type[jid];
+      int da = jnt_dofadr[jid];
+      if (jt == JNT_FREE || jt == JNT_BALL) {
+        if (jt == JNT_FREE) {
+          for (int k = 0; k < 18; k++) S[off::CDOFDOT + 6*da + k] = 0;
+          for (int k = 0; k < 3; k++)
+            for (int c = 0; c < 6; c++)
+              cvel[c] += S[off::CDOF + 6*(da + k) + c]*S[off::QVEL + da + k];
+          da += 3;
+        }
+        real cd[18], dd[18];
+        for (int k = 0; k < 18; k++) cd[k] = S[off::CDOF + 6*da + k];
+        for (int k = 0; k < 3; k++) cross_motion(dd + 6*k, cvel, cd + 6*k);
+        for (int k = 0; k < 18; k++) S[off::CDOFDOT + 6*da + k] = dd[k];
+        for (int k = 0; k < 3; k++) {
+          const real qv = S[off::QVEL + da + k];
+          for (int c = 0; c < 6; c++) { cvel[c] += cd[6*k + c]*qv; cacc[c] += dd[6*k + c]*qv; }
+        }
+      } else {
+        real cd[6], dd[6];
+        for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*da + k];
+        cross_motion(dd, cvel, cd);
+        const real qv = S[off::QVEL + da];
+        for (int c = 0; c < 6; c++) {
+          S[off::CDOFDOT + 6*da + c] = dd[c];
+          cvel[c] += cd[c]*qv; cacc[c] += dd[c]*qv;
+        }
+      }
+    }
+    for (int k = 0; k < 6; k++) { S[off::CVEL + 6*i + k] = cvel[k]; S[off::CACC + 6*i + k] = cacc[k]; }
+  }
+  __device__ void com_vel() {
+    if (l == 0) {
+      for (int k = 0; k < 6; k++) { S[off::CVEL + k] = 0; S[off::CACC + k] = 0; }
+      if (!(DISABLEFLAGS & DSBL_GRAVITY))
+        for (int k = 0; k < 3; k++) S[off::CACC + 3 + k] = -R(gravity[k]);
+    }
+    gsync();
+    for (int lev = 0; lev < NLEVEL; lev++) {
+      for (int idx = level_adr[lev] + l; idx < level_adr[lev + 1]; idx += G)
+        vel_body(level_body[idx]);
+      gsync();
+    }
+  }
+
+  // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
+  __device__ void smooth_forces(bool actuation) {
+    for (int i = l; i < NBODY; i += G) {
+      real f[6];
+      if (i == 0) { for (int k = 0; k < 6; k++) f[k] = 0; }
+      else {
+        real ci[10], v[6], acc[6], tmp[6], tmp1[6];
+        for (int k = 0; k < 10; k++) ci[k] = S[off::CINERT + 10*i + k];
+        for (int k = 0; k < 6; k++) { v[k] = S[off::CVEL + 6*i + k]; acc[k] = S[off::CACC + 6*i + k]; }
+        mul_inert_vec(f, ci, acc);
+        mul_inert_vec(tmp, ci, v);
+        cross_force(tmp1, v, tmp);
+        for (int k = 0; k < 6; k++) f[k] += tmp1[k];
+      }
+      for (int k = 0; k < 6; k++) S[off::CFRC + 6*i + k] = f[k];
+    }
+    gsync();
+    // bias force of dof i = cdof_i . (sum of cfrc over the subtree of its body)
+    for (int i = l; i < NV; i += G) {
+      const int b = dof_bodyid[i], n = body_subtree_n[b];
+      real f[6] = {0, 0, 0, 0, 0, 0}, cd[6];
+      for (int j = b; j < b + n; j++)
+        for (int k = 0; k < 6; k++) f[k] += S[off::CFRC + 6*j + k];
+      for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*i + k];
+      real fs = -dot6(cd, f);
+      if (!(DISABLEFLAGS & DSBL_PASSIVE)) {
+        const int j = dof_jntid[i], jt = jnt_type[j];
+        if (jnt_stiffness[j] != 0 && (jt == JNT_SLIDE || jt == JNT_HINGE)) {
+          const int qa = jnt_qposadr[j];
+          fs -= R(jnt_stiffness[j])*(S[off::QPOS + qa] - R(qpos_spring[qa]));
+        }
+        fs -= R(dof_damping[i])*S[off::QVEL + i];
+      }
+      if (actuation && !(DISABLEFLAGS & DSBL_ACTUATION)) {
+        for (int u = 0; u < NU; u++) {
+          const int j = actuator_trnid[u], dof = jnt_dofadr[j];
+          if (dof != i) continue;
+          const real gear = R(actuator_gear[u]);
+          real c = S[off::CTRL + u];
+          if (actuator_ctrllimited[u] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
+            c = clampr(c, R(actuator_ctrlrange[2*u]), R(actuator_ctrlrange[2*u + 1]));
+          real force = R(actuator_gainprm[3*u])*c;
+          if (actuator_biastype[u] == 1)
+            force += R(actuator_biasprm[3*u]) +
+                     R(actuator_biasprm[3*u + 1])*gear*S[off::QPOS + jnt_qposadr[j]] +
+                     R(actuator_biasprm[3*u + 2])*gear*S[off::QVEL + dof];
+          if (actuator_forcelimited[u])
+            force = clampr(force, R(actuator_forcerange[2*u]), R(actuator_forcerange[2*u + 1]));
+          fs += gear*force;
+        }
+      }
+      S[off::FS + i] = fs;
+    }
+    gsync();
+    PROF(PH_SMOOTH);
+    Rows L;
+    rows_load(L, off::MM);
+    if (rows_chol(L)) warn |= WARN_INERTIA;
+    PROF(PH_FACM);
+    real b[RNV];
+    _Pragma("unroll")
+    for (int t = 0; t < RNV; t++) b[t] = l + t*G < NV ? S[off::FS + l + t*G] : R(0);
+    rows_solve(L, off::HH, b);
+    _Pragma("unroll")
+    for (int t = 0; t < RNV; t++) if (l + t*G < NV) S[off::QAS + l + t*G] = b[t];
+    gsync();
+    PROF(PH_SOLVE);
+  }
+
+  __device__ void subtree_vel() {
+    // momentum of every body about the world origin frame, then range sums
+    for (int i = l; i < NBODY; i += G) {
+      real dif[3], t[3], w[3];
+      const real* com = S + off::SUBCOM + 3*body_rootid[i];
+      for (int k = 0; k < 3; k++) { dif[k] = S[off::XIPOS + 3*i + k] - com[k]; w[k] = S[off::CVEL + 6*i + k]; }
+      cross3(t, w, dif);
+      for (int k = 0; k < 3; k++)
+        S[off::CFRC + 3*i + k] = R(body_mass[i])*(S[off::CVEL + 6*i + 3 + k] + t[k]);
+    }
+    gsync();
+    for (int i = l; i < NBODY; i += G) {
+      real acc[3] = {0, 0, 0};
+      const int n = body_subtree_n[i];
+      for (int j = i; j < i + n; j++)
+        for (int k = 0; k < 3; k++) acc[k] += S[off::CFRC + 3*j + k];
+      const real inv = R(1.0/(body_subtreemass[i] < 1e-15 ? 1e-15 : body_subtreemass[i]));
+      for (int k = 0; k < 3; k++) S[off::SLV + 3*i + k] = acc[k]*inv;
+    }
+    gsync();
+  }
+
+  // ---- constraints -----------------------------------------------------------
+  // Rows are created with their metadata parked in the solver slots
+  // (CR_D <- R, CR_AREF <- K*imp*(pos - margin), CR_JAR <- B); finish_rows()
+  // turns that into D and aref once J is complete.
+  __device__ void row_meta(int r, real pm, real K, real B, real imp, real Rrow) {
+    real* row = S + off::ROWS + r*CRW;
+    row[CR_D] = Rrow; row[CR_AREF] = K*imp*pm; row[CR_JAR] = B;
+  }
+
+  __device__ void limit_rows() {
+    if (DISABLEFLAGS & (DSBL_LIMIT | DSBL_CONSTRAINT)) return;
+    for (int base = 0; base < NLIMIT; base += G) {
+      const int li = base + l;
+      int cnt = 0;
+      real dist[2] = {0, 0};
+      int j = 0, dof = 0;
+      real margin = 0;
+      if (li < NLIMIT) {
+        j = limit_jnt[li];
+        dof = jnt_dofadr[j];
+        margin = R(jnt_margin[j]);
+        const real q = S[off::QPOS + jnt_qposadr[j]];
+        dist[0] = q - R(jnt_range[2*j]);
+        dist[1] = R(jnt_range[2*j + 1]) - q;
+        cnt = (dist[0] < margin ? 1 : 0) + (dist[1] < margin ? 1 : 0);
+      }
+      int total;
+      int r = nefc + gscan(cnt, l, total);
+      for (int side = 0; side < 2; side++) {
+        if (li >= NLIMIT || !(dist[side] < margin)) continue;
+        if (r >= NEFC_MAX) { warn |= WARN_CNSTRFULL; continue; }
+        real* row = S + off::ROWS + r*CRW;
+        for (int k = 0; k < NV; k++) row[k] = 0;
+        row[dof] = side == 0 ? R(1) : R(-1);
+        const real pm = dist[side] - margin;
+        const real imp = impedance(limit_solimp + 5*li, pm);
+        row_meta(r, pm, R(limit_K[li]), R(limit_B[li]), imp,
+                 (1 - imp)*R(dof_invweight0[dof])/imp);
+        r++;
+      }
+      nefc += total;
+      if (nefc > NEFC_MAX) nefc = NEFC_MAX;
+    }
+    warn = (unsigned)gor_bits(warn);
+  }
+  __device__ unsigned gor_bits(unsigned w) {
+    int x = (int)w;
+#ifndef DMC_HOST_SHIM
+    if (G >= 16) {
+      x |= dpp<DPP_XOR1>(x);
+      x |= dpp<DPP_XOR2>(x);
+      x |= dpp<DPP_HALF_MIRROR>(x);
+      x |= dpp<DPP_MIRROR>(x);
+      if (G == 64) x = gbcast_bits(x, 0) | gbcast_bits(x, 16) | gbcast_bits(x, 32) | gbcast_bits(x, 48);
+      else for (int m = 16; m < G; m <<= 1) x |= gxor(x, m);
+      return (unsigned)x;
+    }
+#endif
+    for (int m = G/2; m > 0; m >>= 1) x |= gxor(x, m);
+    return (unsigned)x;
+  }
+
+  // narrowphase over the static pair list, strided over the lanes; an ordered
+  // prefix sum per stride keeps the contact list in pair order
+  __device__ void detect_contacts() {
+    if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return;
+    for (int g = l; g < NGEOM; g += G) {
+      const int b = geom_bodyid[g];
+      real gp[3] = {R(geom_pos[3*g]), R(geom_pos[3*g + 1]), R(geom_pos[3*g + 2])};
+      real gq[4] = {R(geom_quat[4*g]), R(geom_quat[4*g + 1]), R(geom_quat[4*g + 2]),
+                    R(geom_quat[4*g + 3])};
+      real v[3], q[4], bq[4], bm[9], gm[9];
+      for (int k = 0; k < 9; k++) bm[k] = S[off::XMAT + 9*b + k];
+      for (int k = 0; k < 4; k++) bq[k] = S[off::XQUAT + 4*b + k];
+      mulmatvec3(v, bm, gp);
+      for (int k = 0; k < 3; k++) S[off::GEOM + 12*g + k] = S[off::XPOS + 3*b + k] + v[k];
+      mulquat(q, bq, gq);
+      normalize4(q);
+      quat2mat(gm, q);
+      for (int k = 0; k < 9; k++) S[off::GEOM + 12*g + 3 + k] = gm[k];
+    }
+    gsync();
+    int nrow_total = nefc;
+    for (int base = 0; base < NPAIR; base += G) {
+      const int p = base + l;
+      RawCon rc[4];
+      int mask = 0;
+      if (p < NPAIR) mask = collide_pair(S + off::GEOM, p, rc);
+      const int cnt = __builtin_popcount((unsigned)mask);
+      int total;
+      int slot = ncon + gscan(cnt, l, total);
+      // rows of the accepted contacts of this lane
+      int nrows = 0;
+      const int per = p < NPAIR ? pair_nrow[p] : 0;
+      const real incl = p < NPAIR ? R(pair_includemargin[p]) : R(0);
+      {
+        int s2 = slot;
+        _Pragma("unroll")
+        for (int c = 0; c < 4; c++) {
+          if (!((mask >> c) & 1)) continue;
+          if (s2 < NCON_MAX && rc[c].dist < incl) nrows += per;
+          s2++;
+        }
+      }
+      int rtotal;
+      int rbase = nrow_total + gscan(nrows, l, rtotal);
+      _Pragma("unroll")
+      for (int c = 0; c < 4; c++) {
+        if (!((mask >> c) & 1)) continue;
+        if (slot >= NCON_MAX) { warn |= WARN_CONTACTFULL; slot++; continue; }
+        real* rec = S + off::CON + slot*CCW;
+        for (int k = 0; k < 3; k++) {
+          rec[k] = rc[c].pos[k]; rec[3 + k] = rc[c].frame[k]; rec[6 + k] = rc[c].frame[3 + k];
+        }
+        rec[CC_DIST] = rc[c].dist;
+        rec[CC_PAIR] = (real)p;
+        const bool has_rows = rc[c].dist < incl;
+        rec[CC_ROW] = has_rows ? (real)rbase : R(-1);
+        if (has_rows) rbase += per;
+        slot++;
+      }
+      ncon += total;
+      if (ncon > NCON_MAX) ncon = NCON_MAX;
+      nrow_total += rtotal;
+    }
+    warn = gor_bits(warn);
+    gsync();
+  }
+
+  // Jacobian columns of all contact rows: lane = dof
+  __device__ void contact_rows() {
+    detect_contacts();
+    PROF(PH_DETECT);
+    for (int c = 0; c < ncon; c++) {
+      const real* rec = S + off::CON + c*CCW;
+      const int r0 = (int)rec[CC_ROW];
+      if (r0 < 0) continue;
+      const int p = (int)rec[CC_PAIR];
+      const real dist = rec[CC_DIST];
+      real pos[3], fin[6], f[9];
+      for (int k = 0; k < 3; k++) { pos[k] = rec[k]; fin[k] = rec[3 + k]; fin[3 + k] = rec[6 + k]; }
+      make_frame(fin, f);
+      const int b1 = pair_b1[p], b2 = pair_b2[p], dim = pair_dim[p];
+      const unsigned m1lo = body_dofmask_lo[b1], m2lo = body_dofmask_lo[b2];
+      const unsigned m1hi = body_dofmask_hi[b1], m2hi = body_dofmask_hi[b2];
+      real off1[3], off2[3];
+      for (int k = 0; k < 3; k++) {
+        off1[k] = pos[k] - S[off::SUBCOM + 3*body_rootid[b1] + k];
+        off2[k] = pos[k] - S[off::SUBCOM + 3*body_rootid[b2] + k];
+      }
+      const real pm = dist - R(pair_includemargin[p]);
+      const real imp = impedance(pair_solimp + 5*p, pm);
+      const real K = R(pair_K[p]), B = R(pair_B[p]);
+      const int nrow = pair_nrow[p];
+      // per-row metadata (one lane); rows past the capacity are dropped
+      const real mu0 = R(pair_friction[5*p]);
+      real R0 = (1 - imp)*R(pair_diag[6*p + 1])/imp;
+      if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
+      const real Rrow = dim == 1 ? (1 - imp)*R(pair_diag[6*p])/imp : 2*mu0*mu0*R0;
+      if (r0 + nrow > NEFC_MAX) warn |= WARN_CNSTRFULL;
+      if (l == 0)
+        for (int r = r0; r < r0 + nrow && r < NEFC_MAX; r++) row_meta(r, pm, K, B, imp, Rrow);
+      real w1[3][3], w2[3][3];
+      for (int d = 0; d < 3; d++) { cross3(w1[d], off1, f + 3*d); cross3(w2[d], off2, f + 3*d); }
+      for (int j = l; j < NV; j += G) {
+        const bool in1 = ((j < 32 ? m1lo >> j : m1hi >> (j - 32)) & 1u) != 0;
+        const bool in2 = ((j < 32 ? m2lo >> j : m2hi >> (j - 32)) & 1u) != 0;
+        real cd[6], jb[3], jt[3];
+        for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*j + k];
+        for (int d = 0; d < 3; d++) {
+          const real* dir = f + 3*d;
+          const real dl = dot3(dir, cd + 3);
+          const real v2 = dl + dot3(w2[d], cd), v1 = dl + dot3(w1[d], cd);
+          jb[d] = (in2 ? v2 : R(0)) - (in1 ? v1 : R(0));
+          const real vr = dot3(dir, cd);
+          jt[d] = (in2 ? vr : R(0)) - (in1 ? vr : R(0));
+        }
+        real* col = S + off::ROWS + j;
+        if (dim == 1) {
+          if (r0 < NEFC_MAX) col[r0*CRW] = jb[0];
+        } else {
+          for (int k = 1; k < dim; k++) {
+            const real mu = R(pair_friction[5*p + k - 1]);
+            const real t = k < 3 ? jb[k] : jt[k - 3];
+            const int r = r0 + 2*(k - 1);
+            if (r < NEFC_MAX) col[r*CRW] = jb[0] + mu*t;
+            if (r + 1 < NEFC_MAX) col[(r + 1)*CRW] = jb[0] - mu*t;
+          }
+        }
+      }
+      nefc = r0 + nrow < NEFC_MAX ? r0 + nrow : NEFC_MAX;
+    }
+    warn = gor_bits(warn);
+    gsync();
+  }
+
+  // D and aref of every row (lane = row): aref = -B (J qvel) - K imp (pos - margin)
+  __device__ void finish_rows() {
+    for (int r = l; r < nefc; r += G) {
+      real* row = S + off::ROWS + r*CRW;
+      real vel = 0;
+      _Pragma("unroll")
+      for (int j = 0; j < NV; j++) vel += row[j]*S[off::QVEL + j];
+      const real Rr = row[CR_D], kip = row[CR_AREF], B = row[CR_JAR];
+      row[CR_AREF] = -B*vel - kip;
+      row[CR_D] = R(1)/(Rr < DMC_MINVAL ? DMC_MINVAL : Rr);
+    }
+    gsync();
+  }
+
+  // ---- Newton solver (same algorithm and stopping rules as solve_newton in
+  // dmc_kernels.hip; sums over dofs and rows are group reductions) -----------
+  struct Ls { real alpha, dcost, d0, d1; };
+  __device__ void ls_eval(Ls& P, real alpha, real q1, real q2) const {
+    real dcost = 0, d0 = 0, d1 = 0;
+    for (int r = l; r < nefc; r += G) {
+      const real* row = S + off::ROWS + r*CRW;
+      const real x0 = row[CR_JAR], v = row[CR_JV], D = row[CR_D];
+      const real x = x0 + alpha*v;
+      const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
+      dcost += R(0.5)*D*(a*a - a0*a0);
+      if (x < 0) { d0 += D*x*v; d1 += D*v*v; }
+    }
+    dcost = gsum(dcost) + alpha*alpha*q2 + alpha*q1;
+    d0 = gsum(d0) + 2*alpha*q2 + q1;
+    d1 = gsum(d1) + 2*q2;
+    P.alpha = alpha; P.dcost = dcost; P.d0 = d0;
+    P.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+  }
+
+  __device__ void solve_newton(real tol) {
+    const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
+    for (int i = l; i < NV; i += G) S[off::MA + i] = mrow_dot(i, off::QACC);
+    gsync();
+    real improvement = 0;
+    bool converged = false;
+    int iter = 0;
+    for (;; iter++) {
+      // constraint forces of the active rows (lane = row)
+      for (int r = l; r < nefc; r += G) {
+        real* row = S + off::ROWS + r*CRW;
+        const real jar = row[CR_JAR];
+        row[CR_F] = jar < 0 ? -row[CR_D]*jar : R(0);
+      }
+      gsync();
+      // lane = dof: qfrc_constraint, gradient and row i of H = M + J^T D J
+      real gn = 0;
+      Rows H;
+      real grad[RNV];
+      {
+        real fc[RNV];
+        rows_load(H, off::MM);
+        _Pragma("unroll")
+        for (int t = 0; t < RNV; t++) fc[t] = 0;
+        for (int r = 0; r < nefc; r++) {
+          const real* row = S + off::ROWS + r*CRW;
+          if (!(row[CR_JAR] < 0)) continue;
+          const real D = row[CR_D], f = row[CR_F];
+          real jr[NVX];
+          _Pragma("unroll")
+          for (int k = 0; k < NV; k++) jr[k] = row[k];
+          _Pragma("unroll")
+          for (int t = 0; t < RNV; t++) {
+            const int i = l + t*G;
+            const real ji = i < NV ? row[i] : R(0);
+            fc[t] += ji*f;
+            const real s = D*ji;
+            _Pragma("unroll")
+            for (int k = 0; k < NV; k++) H.a[t][k] += s*jr[k];
+          }
+        }
+        _Pragma("unroll")
+        for (int t = 0; t < RNV; t++) {
+          const int i = l + t*G;
+          grad[t] = 0;
+          if (i < NV) {
+            S[off::FC + i] = fc[t];
+            grad[t] = S[off::MA + i] - S[off::FS + i] - fc[t];
+            gn += grad[t]*grad[t];
+          }
+        }
+      }
+      gn = gsum(gn);
+      gsync();
+      PROF(PH_HESS);
+      if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
+      if (iter >= ITERATIONS) break;
+      rows_chol(H);
+      PROF(PH_FACH);
+      _Pragma("unroll")
+      for (int t = 0; t < RNV; t++) grad[t] = -grad[t];
+      rows_solve(H, off::HH, grad);
+      _Pragma("unroll")
+      for (int t = 0; t < RNV; t++) if (l + t*G < NV) S[off::SEARCH + l + t*G] = grad[t];
+      gsync();
+      PROF(PH_SOLVE);
+      real sn = 0, q1 = 0, q2 = 0;
+      for (int i = l; i < NV; i += G) {
+        const real si = S[off::SEARCH + i];
+        const real mv = mrow_dot(i, off::SEARCH);
+        S[off::MV + i] = mv;
+        sn += si*si;
+        q1 += si*(S[off::MA + i] - S[off::FS + i]);
+        q2 += R(0.5)*si*mv;
+      }
+      sn = sqrt(gsum(sn)); q1 = gsum(q1); q2 = gsum(q2);
+      if (sn < DMC_MINVAL) break;
+      const real gtol = tol*R(0.01)*sn/scale;
+      for (int r = l; r < nefc; r += G) {
+        real* row = S + off::ROWS + r*CRW;
+        real sacc = 0;
+        _Pragma("unroll")
+        for (int j = 0; j < NV; j++) sacc += row[j]*S[off::SEARCH + j];
+        row[CR_JV] = sacc;
+      }
+      gsync();
+      // exact line search: safeguarded Newton on the directional derivative
+      Ls p0, p, best;
+      ls_eval(p0, 0, q1, q2);
+      if (!(p0.d0 < 0)) break;
+      best = p0;
+      real lo = 0, hi = 0, a = -p0.d0/p0.d1;
+      bool have_hi = false;
+      const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
+      for (int it = 0; it < (DMC_F32_RULES ? 20 : 50); it++) {
+        ls_eval(p, a, q1, q2);
+        if (p.dcost < best.dcost) best = p;
+        if (fabs(p.d0) < dtol) break;
+        if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
+        real an = a - p.d0/p.d1;
+        if (have_hi) {
+          if (!(an > lo && an < hi)) an = R(0.5)*(lo + hi);
+          if (hi - lo < R(1e-6)*hi) break;
+        } else if (an <= lo) {
+          an = 2*a;
+        }
+        a = an;
+      }
+      const real alpha = best.alpha;
+      PROF(PH_LS);
+      if (alpha == 0) break;
+      improvement = -best.dcost;
+      for (int i = l; i < NV; i += G) {
+        S[off::QACC + i] += alpha*S[off::SEARCH + i];
+        S[off::MA + i] += alpha*S[off::MV + i];
+      }
+      bool changed = false;
+      for (int r = l; r < nefc; r += G) {
+        real* row = S + off::ROWS + r*CRW;
+        const real x0 = row[CR_JAR];
+        const real x1 = x0 + alpha*row[CR_JV];
+        changed |= (x0 < 0) != (x1 < 0);
+        row[CR_JAR] = x1;
+      }
+      changed = gany(changed);
+      gsync();
+      if (DMC_F32_RULES && !changed && fabs(alpha - 1) < R(1e-3)) converged = true;
+      PROF(PH_UPD);
+    }
+    iters = iter;
+  }
+
+  // forward dynamics at (qpos, qvel, ctrl): qacc, qfrc_smooth, qfrc_constraint
+  __device__ void forward(bool actuation, real tol) {
+    PROF(PH_EULER);
+    kinematics();
+    PROF(PH_KIN);
+    com_pos();
+    PROF(PH_COM);
+    crb_matrix();
+    com_vel();
+    PROF(PH_VEL);
+    smooth_forces(actuation);
+    PROF(PH_SMOOTH);
+    ncon = 0; nefc = 0; iters = 0;
+    limit_rows();
+    PROF(PH_LIMIT);
+    if (NPAIR > 0) contact_rows();
+    PROF(PH_CROWS);
+    finish_rows();
+    PROF(PH_FINISH);
+    if (nefc == 0) {
+      for (int i = l; i < NV; i += G) { S[off::QACC + i] = S[off::QAS + i]; S[off::FC + i] = 0; }
+      gsync();
+    } else {
+      // warmstart: the better of the previous qacc and the unconstrained one
+      const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
+      real cw = 0, cs = 0;
+      if (try_warm) {
+        for (int i = l; i < NV; i += G)
+          cw += R(0.5)*(mrow_dot(i, off::WARM) - S[off::FS + i])*
+                (S[off::WARM + i] - S[off::QAS + i]);
+      }
+      for (int r = l; r < nefc; r += G) {
+        real* row = S + off::ROWS + r*CRW;
+        real jw = 0, js = 0;
+        _Pragma("unroll")
+        for (int j = 0; j < NV; j++) {
+          const real v = row[j];
+          jw += v*S[off::WARM + j]; js += v*S[off::QAS + j];
+        }
+        const real aref = row[CR_AREF], D = row[CR_D];
+        jw -= aref; js -= aref;
+        if (jw < 0) cw += R(0.5)*D*jw*jw;
+        if (js < 0) cs += R(0.5)*D*js*js;
+        row[CR_JAR] = jw; row[CR_JV] = js;
+      }
+      cw = gsum(cw); cs = gsum(cs);
+      const bool use_warm = try_warm && !(cw > cs);
+      for (int i = l; i < NV; i += G)
+        S[off::QACC + i] = use_warm ? S[off::WARM + i] : S[off::QAS + i];
+      if (!use_warm)
+        for (int r = l; r < nefc; r += G) {
+          real* row = S + off::ROWS + r*CRW;
+          row[CR_JAR] = row[CR_JV];
+        }
+      gsync();
+      PROF(PH_WARM);
+      solve_newton(tol);
+    }
+    for (int i = l; i < NV; i += G) S[off::WARM + i] = S[off::QACC + i];
+    gsync();
+  }
+
+  // qpos += h * qvel on the configuration manifold (lane = joint); qvel at `v`
+  __device__ void integrate_pos(int v, real h) {
+    for (int j = l; j < NJNT; j += G) {
+      const int qa = jnt_qposadr[j], da = jnt_dofadr[j], jt = jnt_type[j];
+      if (jt == JNT_FREE || jt == JNT_BALL) {
+        int q = qa, d = da;
+        if (jt == JNT_FREE) {
+          for (int k = 0; k < 3; k++) S[off::QPOS + qa + k] += h*S[v + da + k];
+          q += 3; d += 3;
+        }
+        real quat[4], w[3];
+        for (int k = 0; k < 4; k++) quat[k] = S[off::QPOS + q + k];
+        for (int k = 0; k < 3; k++) w[k] = S[v + d + k];
+        quat_integrate(quat, w, h);
+        for (int k = 0; k < 4; k++) S[off::QPOS + q + k] = quat[k];
+      } else {
+        S[off::QPOS + qa] += h*S[v + da];
+      }
+    }
+    gsync();
+  }
+
+  __device__ void reset_state() {   // mj_resetData
+    for (int i = l; i < NQ; i += G) S[off::QPOS + i] = R(qpos0[i]);
+    for (int i = l; i < NV; i += G) { S[off::QVEL + i] = 0; S[off::WARM + i] = 0; }
+    for (int i = l; i < NU; i += G) S[off::CTRL + i] = 0;
+    time = 0;
+    gsync();
+  }
+  __device__ bool check_state() {   // mj_checkPos / mj_checkVel
+    bool bp = false, bv = false;
+    for (int i = l; i < NQ; i += G) bp |= bad(S[off::QPOS + i]);
+    for (int i = l; i < NV; i += G) bv |= bad(S[off::QVEL + i]);
+    bp = gany(bp); bv = gany(bv);
+    if (bp) { warn |= WARN_BADQPOS; reset_state(); }
+    else if (bv) { warn |= WARN_BADQVEL; reset_state(); }
+    return bp || bv;
+  }
+  __device__ bool bad_qacc() {
+    bool ba = false;
+    for (int i = l; i < NV; i += G) ba |= bad(S[off::QACC + i]);
+    return gany(ba);
+  }
+
+  // one `Physics.step()`
+  __device__ void physics_step(real tol) {
+    const real h = R(timestep);
+    check_state();
+    if (!RK4) {
+      forward(true, tol);
+      if (bad_qacc()) { warn |= WARN_BADQACC; reset_state(); return; }
+      bool damped = false;
+      for (int i = 0; i < NV; i++) damped |= dof_damping[i] > 0;
+      int src = off::QACC;
+      if (damped) {   // implicit in the joint damping: (M + h D) a = f
+        Rows A;
+        rows_load(A, off::MM);
+        real rhs[RNV];
+        _Pragma("unroll")
+        for (int t = 0; t < RNV; t++) {
+          const int i = l + t*G;
+          rhs[t] = 0;
+          _Pragma("unroll")
+          for (int k = 0; k < NV; k++)
+            if (i == k) A.a[t][k] += h*R(dof_damping[k]);
+          if (i < NV) rhs[t] = S[off::FS + i] + S[off::FC + i];
+        }
+        rows_chol(A);
+        rows_solve(A, off::HH, rhs);
+        _Pragma("unroll")
+        for (int t = 0; t < RNV; t++) if (l + t*G < NV) S[off::GRAD + l + t*G] = rhs[t];
+        gsync();
+        src = off::GRAD;
+      }
+      for (int i = l; i < NV; i += G) S[off::QVEL + i] += h*S[src + i];
+      gsync();
+      integrate_pos(off::QVEL, h);
+      time += h;
+    } else {
+      const real t0 = time;
+      for (int i = l; i < NQ; i += G) S[off::Q0 + i] = S[off::QPOS + i];
+      for (int i = l; i < NV; i += G) S[off::V0 + i] = S[off::QVEL + i];
+      gsync();
+      forward(true, tol);
+      if (bad_qacc()) { warn |= WARN_BADQACC; reset_state(); return; }
+      for (int i = l; i < NV; i += G) {
+        S[off::FV + i] = S[off::QVEL + i]; S[off::FA + i] = S[off::QACC + i];
+      }
+      gsync();
+      for (int s = 1; s < 4; s++) {
+        const real a = s == 3 ? R(1) : R(0.5);
+        for (int i = l; i < NV; i += G) {
+          S[off::DV + i] = a*S[off::FV + (s - 1)*NV + i];
+          S[off::QVEL + i] = S[off::V0 + i] + h*a*S[off::FA + (s - 1)*NV + i];
+        }
+        for (int i = l; i < NQ; i += G) S[off::QPOS + i] = S[off::Q0 + i];
+        gsync();
+        integrate_pos(off::DV, h);
+        forward(true, tol);
+        for (int i = l; i < NV; i += G) {
+          S[off::FV + s*NV + i] = S[off::QVEL + i]; S[off::FA + s*NV + i] = S[off::QACC + i];
+        }
+        gsync();
+      }
+      for (int i = l; i < NV; i += G) {
+        const real* Fv = S + off::FV + i;
+        const real* Fa = S + off::FA + i;
+        S[off::DV + i] = (Fv[0] + 2*Fv[NV] + 2*Fv[2*NV] + Fv[3*NV])*R(1.0/6.0);
+        const real acc = (Fa[0] + 2*Fa[NV] + 2*Fa[2*NV] + Fa[3*NV])*R(1.0/6.0);
+        S[off::QVEL + i] = S[off::V0 + i] + h*acc;
+      }
+      for (int i = l; i < NQ; i += G) S[off::QPOS + i] = S[off::Q0 + i];
+      gsync();
+      integrate_pos(off::DV, h);
+      time = t0 + h;
+    }
+  }
+
+  __device__ void observe_stage() {
+    check_state();
+    kinematics();
+    com_pos();
+    com_vel();
+    subtree_vel();
+  }
+
+  // ---- HBM I/O ---------------------------------------------------------------
+  __device__ void load(const DmcArgs& a, int e) {
+    const long long n = a.nenv;
+    for (int i = l; i < NQ; i += G) S[off::QPOS + i] = a.qpos[i*n + e];
+    for (int i = l; i < NV; i += G) {
+      S[off::QVEL + i] = a.qvel[i*n + e]; S[off::WARM + i] = a.warm[i*n + e];
+    }
+    time = a.time[e];
+    warn = 0; ncon = 0; nefc = 0; iters = 0;
+  }
+  __device__ void store(const DmcArgs& a, int e) {
+    const long long n = a.nenv;
+    for (int i = l; i < NQ; i += G) a.qpos[i*n + e] = S[off::QPOS + i];
+    for (int i = l; i < NV; i += G) {
+      a.qvel[i*n + e] = S[off::QVEL + i]; a.warm[i*n + e] = S[off::WARM + i];
+    }
+    if (l == 0) {
+      a.time[e] = time;
+      if (warn) a.warn[e] |= warn;
+    }
+  }
+  __device__ void outputs(const DmcArgs& a, int e, bool accumulate) {
+    const long long n = a.nenv;
+    if (l == 0) {
+      const EnvView V = {S + off::QPOS, S + off::QVEL, S + off::CTRL, S + off::XPOS,
+                         S + off::XMAT, S + off::SLV};
+      const real rew = task_outputs(V, a, S + off::OBSV);
+      a.reward[e] = rew;
+      if (accumulate) a.episode_return[e] += rew;
+      a.stats[e] = ncon; a.stats[n + e] = nefc; a.stats[2*n + e] = iters;
+    }
+    gsync();
+    for (int k = l; k < NOBS; k += G)
+      a.obs[(long long)k*a.obs_sk + (long long)e*a.obs_se] = S[off::OBSV + k];
+    for (int s = 0; s < NSENSOR; s++) {
+      const int adr = sensor_adr[s], o = sensor_objid[s], ty = sensor_type[s];
+      if (ty == 35 || ty == 34) {
+        const int src = ty == 35 ? off::SLV : off::SUBCOM;
+        if (l < 3) a.sensordata[(adr + l)*n + e] = S[src + 3*o + l];
+      } else if (l == 0) {
+        if (ty == 8) a.sensordata[adr*n + e] = S[off::QPOS + jnt_qposadr[o]];
+        else if (ty == 9) a.sensordata[adr*n + e] = S[off::QVEL + jnt_dofadr[o]];
+      }
+    }
+    if (a.xpos) for (int i = l; i < NBODY*3; i += G) a.xpos[i*n + e] = S[off::XPOS + i];
+    if (a.xmat) for (int i = l; i < NBODY*9; i += G) a.xmat[i*n + e] = S[off::XMAT + i];
+  }
+};
+
+__shared__ real coop_lds[ENV_WORDS*EPB];
+
+// nsub x Physics.step, then observation + reward of the new state
+extern "C" __global__ void __launch_bounds__(64)
+dmc_step(DmcArgs a) {
+  stage_tables();
+  const int slot = threadIdx.x/G;
+  const int e = blockIdx.x*EPB + slot;
+  if (e >= a.nenv) return;               // whole groups leave together
+  Coop C;
+  C.S = coop_lds + slot*ENV_WORDS;
+  C.l = threadIdx.x % G;
+  const int l = C.l;
+  real* S = C.S;
+  const long long n = a.nenv;
+  C.load(a, e);
+  if (a.flags & 1) {
+    bool bc = false;
+    for (int i = l; i < NU; i += G) {
+      const real c = a.ctrl[i*a.ctrl_sk + (long long)e*a.ctrl_se];
+      S[off::CTRL + i] = c;
+      bc |= bad(c);
+    }
+    if (gany(bc)) {   // mj_fwdActuation's ctrl check: warn and zero the controls
+      C.warn |= WARN_BADCTRL;
+      for (int i = l; i < NU; i += G) S[off::CTRL + i] = 0;
+    }
+    for (int i = l; i < NU; i += G) a.ctrl_store[i*n + e] = S[off::CTRL + i];
+  } else {
+    for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[i*n + e];
+  }
+  gsync();
+  const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
+#ifdef DMC_COOP_PROFILE
+  for (int k = 0; k < PH_N; k++) C.tprof[k] = 0;
+  C.tlast = wall_clock64();
+#endif
+  for (int s = 0; s < a.nsub; s++) C.physics_step(tol);
+#ifdef DMC_COOP_PROFILE
+  { const long long t_ = wall_clock64(); C.tprof[PH_EULER] += t_ - C.tlast; C.tlast = t_; }
+#endif
+  if (a.qacc) for (int i = l; i < NV; i += G) a.qacc[i*n + e] = S[off::QACC + i];
+  if (!(a.flags & 2)) {
+    C.observe_stage();
+    C.outputs(a, e, true);
+  }
+#ifdef DMC_COOP_PROFILE
+  { const long long t_ = wall_clock64(); C.tprof[PH_OBS] += t_ - C.tlast; }
+  if (l == 0) for (int k = 0; k < PH_N && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = (real)C.tprof[k];
+#endif
+  C.store(a, e);
+}
+
+// observation / reward / sensors of the current state (reset, after_reset)
+extern "C" __global__ void __launch_bounds__(64)
+dmc_observe(DmcArgs a) {
+  stage_tables();
+  const int slot = threadIdx.x/G;
+  const int e = blockIdx.x*EPB + slot;
+  if (e >= a.nenv) return;
+  Coop C;
+  C.S = coop_lds + slot*ENV_WORDS;
+  C.l = threadIdx.x % G;
+  const int l = C.l;
+  real* S = C.S;
+  const long long n = a.nenv;
+  C.load(a, e);
+  for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[i*n + e];
+  gsync();
+  C.observe_stage();
+  if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
+    C.ncon = 0; C.nefc = 0;
+    if (NPAIR > 0) C.detect_contacts();
+  }
+  C.outputs(a, e, false);
+  C.store(a, e);
+}
+
+extern "C" __device__ const int dmc_info[16] = {
+    1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
+    1 /*workspace reals per env: none, everything is in LDS*/, TASK, NCON_MAX, NEFC_MAX,
+    INTEGRATOR, NPAIR, EPB /*envs per 64-lane workgroup*/, G};

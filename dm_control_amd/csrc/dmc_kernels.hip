@@ -1487,7 +1487,8 @@ DEV real tolerance(real x, real lower, real upper, real margin, int sigmoid,
 
 #define OBS(k) obs[k]
 
-DEV real task_outputs(const Env& E, const DmcArgs& a, real* obs) {
+template <class EnvT>
+DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
   real reward = 0;
   const real inf = R(1e30);
   if (TASK == TASK_CARTPOLE) {
@@ -1610,8 +1611,10 @@ DEV real task_outputs(const Env& E, const DmcArgs& a, real* obs) {
 }
 
 // ---------------------------------------------------------------------------
-// kernels
+// kernels (one env per lane; csrc/dmc_coop.hip includes this file for the
+// helpers above and supplies its own dmc_step / dmc_observe)
 // ---------------------------------------------------------------------------
+#ifndef DMC_COOP_BUILD
 DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   const long long n = a.nenv;
   DMC_UNROLL
@@ -1757,6 +1760,8 @@ dmc_observe(DmcArgs a) {
   store_env(E, a, e, time);
 }
 
+#endif  // !DMC_COOP_BUILD
+
 // stateless counter-based generator for on-device episode initialisation
 DEV uint32_t mix32(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
@@ -1838,8 +1843,10 @@ dmc_init_episode(DmcArgs a) {
   a.episode_return[e] = 0;
 }
 
+#ifndef DMC_COOP_BUILD
 // self-description read by dmc_api.cpp through hipModuleGetGlobal
 extern "C" __device__ const int dmc_info[16] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     (WS_WORDS > 0 ? WS_WORDS : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
-    INTEGRATOR, NPAIR, 0, 0};
+    INTEGRATOR, NPAIR, 64 /*envs per 64-lane workgroup of dmc_step/dmc_observe*/, 0};
+#endif

@@ -59,9 +59,9 @@ class Physics(engine.Physics):
   """Physics with the Humanoid helpers (humanoid.py:93-129)."""
 
   _TASK = codegen.TASK_HUMANOID
-  # the static (unrolled) build of this model spills heavily but is validated
-  # against the oracle by tests/test_gpu_parity.py in fp32 and fp64
-  _BUILD_MODE = 'unrolled'
+  # 27 dofs: one env per 64-lane group with its working set in LDS
+  # (csrc/dmc_coop.hip); the one-lane build spills the 27 x 27 matrices
+  _BUILD_MODE = 'coop'
 
   def torso_upright(self):
     return self.named.data.xmat['torso', 'zz']

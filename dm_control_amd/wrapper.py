@@ -33,7 +33,8 @@ class Error(Exception):
 class ModelInfo(ctypes.Structure):
   _fields_ = [(n, ctypes.c_int) for n in (
       'abi', 'real_size', 'nq', 'nv', 'nu', 'nbody', 'nobs', 'nsensordata',
-      'ws_per_env', 'task', 'ncon_max', 'nefc_max', 'integrator', 'npair')]
+      'ws_per_env', 'task', 'ncon_max', 'nefc_max', 'integrator', 'npair',
+      'lanes_per_env')]
 
 
 # every symbol declared in include/dmc_hip.h: (restype, argtypes)

@@ -73,7 +73,8 @@ enum dmc_warn_bit {
 /* sizes of a loaded model (read back from the code object) */
 typedef struct dmc_model_info {
   int abi, real_size, nq, nv, nu, nbody, nobs, nsensordata, ws_per_env, task,
-      ncon_max, nefc_max, integrator, npair;
+      ncon_max, nefc_max, integrator, npair,
+      lanes_per_env; /* 1, or the group size of a several-lanes-per-env build */
 } dmc_model_info;
 
 int dmc_version(void);

@@ -11,7 +11,7 @@ TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
          'humanoid': codegen.TASK_HUMANOID, 'walker': codegen.TASK_WALKER,
          'pendulum': codegen.TASK_PENDULUM}
 # build mode per suite model (humanoid: see suite/humanoid.py)
-MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'unrolled',
+MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'coop',
          'walker': 'auto', 'pendulum': 'auto'}
 
 

@@ -1,4 +1,4 @@
-"""Sanitizer run of the kernel SOURCE on the host (no GPU needed).
+"""Sanitizer runs of the kernel SOURCES on the host (no GPU needed).
 
 GPU AddressSanitizer is not available, so csrc/dmc_kernels.hip is compiled as
 plain C++ through tests/host_shim/shim.h (one lane, one workgroup, fp64) with
@@ -90,3 +90,87 @@ def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path
     np.testing.assert_allclose(state[:model.nq], d.qpos, rtol=0, atol=1e-9)
     np.testing.assert_allclose(state[model.nq:], d.qvel, rtol=0, atol=1e-8)
   assert touched      # constraint rows (LDS and HBM tiers) were exercised
+
+
+# ---------------------------------------------------------------------------
+# several lanes per env (csrc/dmc_coop.hip): one OS thread per lane
+# ---------------------------------------------------------------------------
+COOP_KERNEL = os.path.join(ROOT, 'dm_control_amd', 'csrc', 'dmc_coop.hip')
+
+
+def _build_coop(model, task, tmp_path, sanitizer, group):
+  header = tmp_path/'model.h'
+  text = codegen.generate_header(model, task, unroll=True)
+  header.write_text(text.replace('static __device__ constexpr',
+                                 'static constexpr'))
+  exe = tmp_path/'harness_coop'
+  cmd = ['g++', '-std=c++17', '-O1', '-g', '-pthread',
+         '-fsanitize=' + sanitizer, '-fno-omit-frame-pointer',
+         '-DDMC_REAL_IS_DOUBLE', '-DDMC_GROUP=%d' % group,
+         '-DDMC_MODEL_HEADER="%s"' % header,
+         '-DDMC_KERNEL_SOURCE="%s"' % COOP_KERNEL,
+         '-I', os.path.join(ROOT, 'dm_control_amd', 'csrc'), '-I', SHIM,
+         '-x', 'c++', os.path.join(SHIM, 'harness_coop.cpp'), '-o', str(exe)]
+  if 'undefined' in sanitizer:
+    cmd.insert(1, '-fno-sanitize-recover=undefined')
+  subprocess.check_call(cmd)
+  return str(exe)
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize('name,sanitizer,group,steps', [
+    ('humanoid', 'address,undefined', 64, 9),
+    ('cheetah', 'thread', 32, 12),
+    ('primitives', 'thread', 32, 20),
+    ('cartpole', 'address,undefined', 64, 6)])
+def test_several_lanes_per_env_source(name, sanitizer, group, steps, tmp_path):
+  """csrc/dmc_coop.hip with one thread per lane (tests/host_shim/shim_coop.h):
+  a phase hand-over is a pthread barrier, so ThreadSanitizer reports any LDS
+  word that crosses lanes without one, AddressSanitizer every index; the
+  trajectories of all envs of the workgroup are compared with the oracle."""
+  nenv = 64//group
+  if name == 'primitives':
+    model, task = compiler.from_xml_string(kat_models.PRIMITIVES), 0
+    q = np.tile(model.qpos0, (nenv, 1))
+    v = np.zeros((nenv, model.nv))
+    q[:, 2], q[:, 9], q[:, 16] = 0.11, 0.2, 0.3
+  else:
+    model, task = helpers.load_model(name), helpers.TASKS[name]
+    q, v = helpers.initial_states(model, name, max(nenv, 2), seed=7)
+    q, v = q[-nenv:], v[-nenv:]
+  exe = _build_coop(model, task, tmp_path, sanitizer, group)
+  args = [exe, str(steps), '1']
+  for e in range(nenv):
+    args += ['%.17g' % x for x in q[e]] + ['%.17g' % x for x in v[e]]
+  env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0',
+             TSAN_OPTIONS='halt_on_error=1')
+  out = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, env=env, timeout=1100)
+  assert out.returncode == 0, out.stderr[-3000:]
+  om = oracle.OracleModel(model)
+  datas = []
+  for e in range(nenv):
+    d = oracle.OracleData(om)
+    d.qpos[:] = q[e]
+    d.qvel[:] = v[e]
+    d.step1()
+    datas.append(d)
+  seen, touched = 0, False
+  for line in out.stdout.splitlines():
+    if not line.startswith('STEP'):
+      continue
+    vals, tail = line.split('|')
+    fields = vals.split()
+    e = int(fields[2])
+    state = np.array([float(x) for x in fields[3:]])
+    ncon, nefc, iters, warn = [int(x) for x in tail.split()]
+    d = datas[e]
+    touched |= d.nefc > 0
+    assert (ncon, nefc) == (d.ncon, d.nefc)
+    d.physics_step()
+    assert warn == 0
+    np.testing.assert_allclose(state[:model.nq], d.qpos, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(state[model.nq:], d.qvel, rtol=0, atol=1e-8)
+    seen += 1
+  assert seen == steps*nenv
+  assert touched or name == 'cartpole'
