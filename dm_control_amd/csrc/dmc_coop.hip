@@ -69,7 +69,7 @@ constexpr int CVEL = CDOF + NVX*6;
 constexpr int MM = CVEL + NBODY*6;
 // tree temporaries that are dead once qfrc_smooth exists; the triangular
 // solves reuse their space as the transposition scratch HH
-constexpr int TMP0 = MM + NVX*NVP;
+constexpr int TMP0 = ((MM + NVX*NVP + 3)/4)*4;   // 16-byte aligned: wide panel loads
 constexpr int XIMAT = TMP0;
 constexpr int XANCHOR = XIMAT + NBODY*9;
 constexpr int XAXIS = XANCHOR + NJX*3;
@@ -80,7 +80,8 @@ constexpr int CACC = CDOFDOT + NVX*6;
 constexpr int CFRC = CACC + NBODY*6;
 constexpr int TMP1 = CFRC + NBODY*6;
 constexpr int HH = TMP0;
-constexpr int TMPEND = TMP1 - TMP0 > NVX*NVP ? TMP1 : TMP0 + NVX*NVP;
+constexpr int HH_WORDS = NVX*NVP > 2*NVX*4 ? NVX*NVP : 2*NVX*4;   // solve scratch / factor panels
+constexpr int TMPEND = TMP1 - TMP0 > HH_WORDS ? TMP1 : TMP0 + HH_WORDS;
 constexpr int FS = TMPEND;              // qfrc_smooth
 constexpr int FC = FS + NVX;            // qfrc_constraint
 constexpr int QAS = FC + NVX;           // qacc_smooth
@@ -318,26 +319,61 @@ struct Coop {
       for (int k = 0; k < NV; k++) A.a[t][k] = i < NV ? S[src + i*NVP + k] : R(0);
     }
   }
-  // in place A = L L^T (right-looking); lane i ends with L[i][0..i-1] and
-  // 1/L[i][i] in a[i]; entries right of the diagonal are dead
-  __device__ int rows_chol(Rows& A) const {
+  // in place A = L L^T; lane i ends with L[i][0..i-1] and 1/L[i][i] in a[i];
+  // entries right of the diagonal are dead.  Right-looking in blocks of CB
+  // columns: inside a block the pivot row travels by register broadcast; the
+  // finished panel (CB values per row) goes to LDS once and every lane reads
+  // row k of it with one wide uniform-address load for the update of its
+  // column k -- one LDS round trip per block instead of one broadcast per
+  // (column, column) pair.  The panel buffer is the solve scratch at `panel`
+  // (two halves used alternately, so one phase boundary per block suffices).
+  static constexpr int CB = 4;
+  __device__ int rows_chol(Rows& A, int panel) {
     int nbad = 0;
     _Pragma("unroll")
-    for (int j = 0; j < NV; j++) {
-      real d = gbcast(A.a[j/G][j], j % G);
-      if (!(d >= DMC_MINVAL)) { d = DMC_MINVAL; nbad++; }
-      const real inv = rsqrt_(d);
-      real lij[RNV];
+    for (int jb = 0; jb < NV; jb += CB) {
+      const int w = NV - jb < CB ? NV - jb : CB;
+      real pl[RNV][CB];
       _Pragma("unroll")
-      for (int t = 0; t < RNV; t++) {
-        lij[t] = A.a[t][j]*inv;
-        A.a[t][j] = (l + t*G == j) ? inv : lij[t];
-      }
-      _Pragma("unroll")
-      for (int k = j + 1; k < NV; k++) {
-        const real lkj = gbcast(lij[k/G], k % G);
+      for (int jj = 0; jj < w; jj++) {
+        const int j = jb + jj;
+        real d = gbcast(A.a[j/G][j], j % G);
+        if (!(d >= DMC_MINVAL)) { d = DMC_MINVAL; nbad++; }
+        const real inv = rsqrt_(d);
         _Pragma("unroll")
-        for (int t = 0; t < RNV; t++) A.a[t][k] -= lij[t]*lkj;
+        for (int t = 0; t < RNV; t++) {
+          pl[t][jj] = A.a[t][j]*inv;
+          A.a[t][j] = (l + t*G == j) ? inv : pl[t][jj];
+        }
+        _Pragma("unroll")
+        for (int k = j + 1; k < jb + w; k++) {
+          const real lkj = gbcast(pl[k/G][jj], k % G);
+          _Pragma("unroll")
+          for (int t = 0; t < RNV; t++) A.a[t][k] -= pl[t][jj]*lkj;
+        }
+      }
+      if (jb + w < NV) {
+        const int buf = panel + ((jb/CB) & 1)*NVX*CB;
+        _Pragma("unroll")
+        for (int t = 0; t < RNV; t++) {
+          const int i = l + t*G;
+          if (i < NV) {
+            _Pragma("unroll")
+            for (int m = 0; m < w; m++) S[buf + i*CB + m] = pl[t][m];
+          }
+        }
+        gsync();
+        _Pragma("unroll")
+        for (int k = jb + w; k < NV; k++) {
+          real pk[CB];
+          _Pragma("unroll")
+          for (int m = 0; m < w; m++) pk[m] = S[buf + k*CB + m];
+          _Pragma("unroll")
+          for (int t = 0; t < RNV; t++) {
+            _Pragma("unroll")
+            for (int m = 0; m < w; m++) A.a[t][k] -= pl[t][m]*pk[m];
+          }
+        }
       }
     }
     return nbad;
@@ -699,7 +735,7 @@ struct Coop {
     PROF(PH_SMOOTH);
     Rows L;
     rows_load(L, off::MM);
-    if (rows_chol(L)) warn |= WARN_INERTIA;
+    if (rows_chol(L, off::HH)) warn |= WARN_INERTIA;
     PROF(PH_FACM);
     real b[RNV];
     _Pragma("unroll")
@@ -1020,7 +1056,7 @@ struct Coop {
       PROF(PH_HESS);
       if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
       if (iter >= ITERATIONS) break;
-      rows_chol(H);
+      rows_chol(H, off::HH);
       PROF(PH_FACH);
       _Pragma("unroll")
       for (int t = 0; t < RNV; t++) grad[t] = -grad[t];
@@ -1224,7 +1260,7 @@ struct Coop {
             if (i == k) A.a[t][k] += h*R(dof_damping[k]);
           if (i < NV) rhs[t] = S[off::FS + i] + S[off::FC + i];
         }
-        rows_chol(A);
+        rows_chol(A, off::HH);
         rows_solve(A, off::HH, rhs);
         _Pragma("unroll")
         for (int t = 0; t < RNV; t++) if (l + t*G < NV) S[off::GRAD + l + t*G] = rhs[t];
@@ -1332,7 +1368,7 @@ struct Coop {
   }
 };
 
-__shared__ real coop_lds[ENV_WORDS*EPB];
+__shared__ __attribute__((aligned(16))) real coop_lds[ENV_WORDS*EPB];
 
 // nsub x Physics.step, then observation + reward of the new state
 extern "C" __global__ void __launch_bounds__(64)

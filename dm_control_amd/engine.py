@@ -244,6 +244,11 @@ class Physics(_control.Physics):
 
   _TASK = codegen.TASK_NONE   # domain subclasses select the fused task
   _BUILD_MODE = 'auto'        # see build.build_model
+  # Batches up to this size use the several-lanes-per-env kernel
+  # (build mode "coop") when the mode is "auto": one env per lane needs >= 64
+  # envs per CU to fill the chip, a group per env fills it at 4 envs per CU.
+  # Measured cross-over per domain; 0 = never.
+  _COOP_MAX_BATCH = 0
 
   def __init__(self, model, batch_size=None, device=0, precision='f32',
                task=None, ncon_max=None, build_mode=None):
@@ -262,6 +267,9 @@ class Physics(_control.Physics):
     self._profile_seconds = 0.0
     self._profile_calls = 0
     self._build_mode = build_mode or self._BUILD_MODE
+    if (build_mode is None and self._build_mode == 'auto' and
+        self._batch_size <= self._COOP_MAX_BATCH):
+      self._build_mode = 'coop'
     path = build.build_model(
         model, self._task_id, precision, ncon_max, mode=self._build_mode,
         lds_budget=build.lds_budget_for(self._batch_size))

@@ -49,6 +49,8 @@ class Physics(engine.Physics):
   """Physics with the Walker helpers (walker.py:79-100)."""
 
   _TASK = codegen.TASK_WALKER
+  # several lanes per env up to this batch size (measured cross-over)
+  _COOP_MAX_BATCH = 8192
 
   def torso_upright(self):
     return self.named.data.xmat['torso', 'zz']
