@@ -20,7 +20,7 @@ import numpy as np
 from dm_control_amd.mjcf import model as mdl
 
 TASK_NONE, TASK_CARTPOLE, TASK_CHEETAH, TASK_HUMANOID = 0, 1, 2, 3
-TASK_WALKER, TASK_PENDULUM = 4, 5
+TASK_WALKER, TASK_PENDULUM, TASK_ACROBOT = 4, 5, 6
 
 _SUPPORTED_PAIRS = {
     (mdl.GEOM_PLANE, mdl.GEOM_SPHERE), (mdl.GEOM_PLANE, mdl.GEOM_CAPSULE),
@@ -134,6 +134,8 @@ def task_bodies(m, task):
     return [m.name2id('torso', 'body')]
   if task == TASK_PENDULUM:
     return [m.name2id('pole', 'body')]
+  if task == TASK_ACROBOT:
+    return [m.name2id('upper_arm', 'body'), m.name2id('lower_arm', 'body')]
   if task == TASK_HUMANOID:
     return [m.name2id(n, 'body') for n in
             ('torso', 'head', 'left_hand', 'left_foot', 'right_hand',
@@ -152,7 +154,20 @@ def observation_size(m, task):
     return 2*(m.nbody - 1) + 1 + m.nv
   if task == TASK_PENDULUM:
     return 3
+  if task == TASK_ACROBOT:
+    return 4 + m.nv
   return m.nq + m.nv
+
+
+def task_sites(m, task):
+  """Sites a task's reward reads: [(body id, local pos[3], size[0])]."""
+  names = {TASK_ACROBOT: ('tip', 'target')}.get(task, ())
+  out = []
+  for n in names:
+    i = m.name2id(n, 'site')
+    out.append((int(m.site_bodyid[i]), [float(v) for v in m.site_pos[i]],
+                float(m.site_size[i][0])))
+  return out
 
 
 def capacities(m, pairs, ncon_max=None):
@@ -292,6 +307,10 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   tr('pair_friction', pair_fric); tr('pair_K', pair_k); tr('pair_B', pair_b)
   tr('pair_solimp', pair_solimp); tr('pair_diag', pair_diag)
   ti('task_body', (task_bodies(m, task) + [0]*6)[:6])
+  sites = task_sites(m, task)
+  ti('task_site_body', [s[0] for s in sites] or [0])
+  tr('task_site_pos', [v for s in sites for v in s[1]] or [0, 0, 0])
+  tr('task_site_size', [s[2] for s in sites] or [0])
   # static ancestor chains (replace pointer-chasing loops over dof_parentid so
   # that fully unrolled code indexes per-lane arrays with compile-time indices)
   chains = []

@@ -82,7 +82,7 @@ enum { WARN_INERTIA = 1, WARN_CONTACTFULL = 2, WARN_CNSTRFULL = 4,
        WARN_BADQPOS = 16, WARN_BADQVEL = 32, WARN_BADQACC = 64,
        WARN_BADCTRL = 128 };
 enum { TASK_NONE = 0, TASK_CARTPOLE = 1, TASK_CHEETAH = 2, TASK_HUMANOID = 3,
-       TASK_WALKER = 4, TASK_PENDULUM = 5 };
+       TASK_WALKER = 4, TASK_PENDULUM = 5, TASK_ACROBOT = 6 };
 
 #define DMC_REALPTR real*
 #define DMC_CREALPTR const real*
@@ -1601,6 +1601,29 @@ DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
     OBS(2) = E.qvel[0];
     reward = tolerance(E.xmat[9*pole + 8], R(0.9902680687415704), R(1), 0,
                        SIG_GAUSSIAN, R(0.1));
+  } else if (TASK == TASK_ACROBOT) {
+    // acrobot.py:62-81,109-126; task_body = upper_arm, lower_arm;
+    // task_site = tip (on lower_arm), target (world)
+    const int upper = task_body[0], lower = task_body[1];
+    OBS(0) = E.xmat[9*upper + 2]; OBS(1) = E.xmat[9*lower + 2];
+    OBS(2) = E.xmat[9*upper + 8]; OBS(3) = E.xmat[9*lower + 8];
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) OBS(4 + i) = E.qvel[i];
+    real d2 = 0;
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      real p[2];
+      DMC_UNROLL
+      for (int s = 0; s < 2; s++) {
+        const int b = task_site_body[s];
+        p[s] = E.xpos[3*b + k] + E.xmat[9*b + 3*k]*R(task_site_pos[3*s]) +
+               E.xmat[9*b + 3*k + 1]*R(task_site_pos[3*s + 1]) +
+               E.xmat[9*b + 3*k + 2]*R(task_site_pos[3*s + 2]);
+      }
+      d2 += (p[1] - p[0])*(p[1] - p[0]);
+    }
+    reward = tolerance(sqrt(d2), 0, R(task_site_size[1]),
+                       (a.task_param_i & 1) ? R(0) : R(1), SIG_GAUSSIAN, R(0.1));
   } else {
     DMC_UNROLL
     for (int i = 0; i < NQ; i++) OBS(i) = E.qpos[i];
@@ -1812,7 +1835,7 @@ dmc_init_episode(DmcArgs a) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) qvel[i] = R(0.01)*rng.normal();
   } else if (TASK == TASK_CHEETAH || TASK == TASK_HUMANOID ||
-             TASK == TASK_WALKER || TASK == TASK_PENDULUM) {
+             TASK == TASK_WALKER || TASK == TASK_PENDULUM || TASK == TASK_ACROBOT) {
     DMC_UNROLL
     for (int j = 0; j < NJNT; j++) {
       const int qa = jnt_qposadr[j];

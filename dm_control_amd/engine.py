@@ -467,6 +467,34 @@ class Physics(_control.Physics):
     new._aux_on = self._aux_on
     return new
 
+  # -- checkpoints ----------------------------------------------
+  def save_checkpoint(self, path):
+    """Writes the integration state of every instance to an `.npz` file.
+
+    qpos, qvel, qacc_warmstart and time are exactly what `mj_step` carries from
+    one step to the next (the warm start matters: it seeds the Newton solver),
+    so a restored batch continues bit-for-bit under the same actions.
+    """
+    b = self._batch
+    np.savez(path, qpos=b.read(wrapper.FIELD_QPOS), qvel=b.read(wrapper.FIELD_QVEL),
+             qacc_warmstart=b.read(wrapper.FIELD_WARMSTART),
+             time=b.read(wrapper.FIELD_TIME),
+             model_hash=np.array(self.model.content_hash()),
+             precision=np.array(self._precision))
+
+  def load_checkpoint(self, path):
+    """Restores a state written by `save_checkpoint` (same model, batch size)."""
+    with np.load(path, allow_pickle=False) as z:
+      if str(z['model_hash']) != self.model.content_hash():
+        raise ValueError('checkpoint was written for a different model')
+      qpos, qvel = z['qpos'], z['qvel']
+      if qpos.shape != (self.model.nq, self._batch_size):
+        raise ValueError('checkpoint holds {} instances, this batch {}'.format(
+            qpos.shape[-1], self._batch_size))
+      self._batch.set_state(qpos=qpos, qvel=qvel, warmstart=z['qacc_warmstart'],
+                            time=z['time'])
+    self._dirty = True
+
   def set_task_params(self, iparam=0, rparams=()):
     self._batch.set_task_params(iparam, rparams)
 

@@ -527,8 +527,12 @@ class _Compiler:
       ft = np.array(_floats(a['fromto'], 6, 'fromto'))
       pos = 0.5*(ft[:3] + ft[3:])
       quat = z_to_quat(ft[:3] - ft[3:])
+    # size: up to 3 numbers, missing ones keep MuJoCo's site default (0.005)
+    size = [0.005, 0.005, 0.005]
+    for k, v in enumerate(a.get('size', '').split()[:3]):
+      size[k] = float(v)
     self.sites.append(dict(name=a.get('name'), body=body_id, pos=pos,
-                           quat=quat))
+                           quat=quat, size=np.array(size)))
 
   # -- assembly -----------------------------------------------------------------
   def compile(self):
@@ -777,6 +781,7 @@ class _Compiler:
     m.site_bodyid = np.array([s['body'] for s in self.sites], np.int32)
     m.site_pos = np.array([s['pos'] for s in self.sites]).reshape(-1, 3)
     m.site_quat = np.array([s['quat'] for s in self.sites]).reshape(-1, 4)
+    m.site_size = np.array([s['size'] for s in self.sites]).reshape(-1, 3)
     self.joints, self.geoms = joints, geoms
 
   def _finish_actuators(self, m):

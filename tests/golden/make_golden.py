@@ -120,10 +120,10 @@ def rewards_golden():
 
 
 def tasks_golden():
-  from dm_control.suite import cartpole, cheetah, humanoid, pendulum, walker
+  from dm_control.suite import acrobot, cartpole, cheetah, humanoid, pendulum, walker
   rs = np.random.RandomState(1)
   out = {'cartpole': [], 'cheetah': [], 'humanoid': [], 'walker': [],
-         'pendulum': []}
+         'pendulum': [], 'acrobot': []}
 
   for _ in range(24):
     x, cos, ctrl = rs.uniform(-2, 2), rs.uniform(-1, 1), rs.uniform(-1.5, 1.5)
@@ -194,6 +194,29 @@ def tasks_golden():
       def pole_vertical(self): return zz
     out['pendulum'].append(dict(
         pole_vertical=zz, reward=float(pendulum.SwingUp(random=0).get_reward(P()))))
+
+  # acrobot draws from its own stream so the records above stay as they were
+  rs = np.random.RandomState(7)
+  for _ in range(16):
+    dist = rs.uniform(0, 0.3) if rs.rand() < 0.4 else rs.uniform(0, 6)
+    hor, ver, vel = rs.uniform(-1, 1, 2), rs.uniform(-1, 1, 2), rs.uniform(-9, 9, 2)
+
+    class P(acrobot.Physics):
+      named = types.SimpleNamespace(model=types.SimpleNamespace(
+          site_size={('target', 0): 0.2}))
+      def to_target(self): return dist
+      def horizontal(self): return hor
+      def vertical(self): return ver
+      def velocity(self): return vel
+    rec = dict(to_target=dist, horizontal=hor.tolist(), vertical=ver.tolist(),
+               velocity=vel.tolist())
+    for sparse in (False, True):
+      t = acrobot.Balance(sparse=sparse, random=0)
+      rec['reward_sparse' if sparse else 'reward_smooth'] = float(t.get_reward(P()))
+      obs = t.get_observation(P())
+      rec['obs_keys'] = list(obs.keys())
+      rec['obs_orientations'] = np.asarray(obs['orientations']).tolist()
+    out['acrobot'].append(rec)
   return out
 
 

@@ -9,10 +9,10 @@ from dm_control_amd.mjcf import compiler
 
 TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
          'humanoid': codegen.TASK_HUMANOID, 'walker': codegen.TASK_WALKER,
-         'pendulum': codegen.TASK_PENDULUM}
+         'pendulum': codegen.TASK_PENDULUM, 'acrobot': codegen.TASK_ACROBOT}
 # build mode per suite model (humanoid: see suite/humanoid.py)
 MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'coop',
-         'walker': 'auto', 'pendulum': 'auto'}
+         'walker': 'auto', 'pendulum': 'auto', 'acrobot': 'auto'}
 
 
 def model_xml(name):
@@ -43,6 +43,9 @@ def initial_states(model, name, nenv, seed):
   elif name == 'pendulum':
     qpos[:, 0] = rs.uniform(-np.pi, np.pi, nenv)
     qvel[:] = rs.randn(nenv, 1)
+  elif name == 'acrobot':
+    qpos[:] = rs.uniform(-np.pi, np.pi, (nenv, 2))
+    qvel[:] = 2*rs.randn(nenv, 2)
   elif name == 'walker':
     lim = model.jnt_limited.astype(bool)
     lo, hi = model.jnt_range[lim].T

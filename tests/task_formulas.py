@@ -72,3 +72,9 @@ def walker_reward(torso_height, torso_upright, horizontal_velocity, move_speed):
 def pendulum_reward(pole_vertical):
   """suite/pendulum.py:119-120."""
   return rewards.tolerance(pole_vertical, (np.cos(np.deg2rad(8)), 1))
+
+
+def acrobot_reward(to_target, sparse, target_radius=0.2):
+  """suite/acrobot.py:116-126."""
+  return rewards.tolerance(to_target, bounds=(0, target_radius),
+                           margin=0 if sparse else 1)

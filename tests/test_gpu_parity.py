@@ -98,7 +98,7 @@ def _teacher_forced(name, precision, nenv, steps, nsub, lds_budget=None,
 
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
                                        ('humanoid', 5), ('walker', 10),
-                                       ('pendulum', 1)])
+                                       ('pendulum', 1), ('acrobot', 1)])
 def test_fp64_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f64', nenv=64, steps=12, nsub=nsub)
   assert e.max() <= 1e-9, e.max()
@@ -106,7 +106,7 @@ def test_fp64_build_matches_oracle_per_step(name, nsub):
 
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
                                        ('humanoid', 5), ('walker', 10),
-                                       ('pendulum', 1)])
+                                       ('pendulum', 1), ('acrobot', 1)])
 def test_fp32_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f32', nenv=128, steps=12, nsub=nsub)
   assert np.median(e) <= 2e-6, np.median(e)
@@ -294,7 +294,9 @@ def test_fused_task_outputs_match_reference_formulas():
                              ('humanoid', 'walk', 32),
                              ('humanoid', 'stand', 32),
                              ('walker', 'run', 32), ('walker', 'stand', 32),
-                             ('pendulum', 'swingup', 64)):
+                             ('pendulum', 'swingup', 64),
+                             ('acrobot', 'swingup', 64),
+                             ('acrobot', 'swingup_sparse', 64)):
     env = suite.load(domain, task, task_kwargs={'random': 4},
                      environment_kwargs={'batch_size': nenv})
     physics = env.physics
@@ -331,6 +333,15 @@ def test_fused_task_outputs_match_reference_formulas():
                                    xmat[i, 1:][:, [0, 2]].ravel(), atol=1e-6)
         np.testing.assert_allclose(ts.observation['height'][i],
                                    xpos[i, torso, 2])
+      elif domain == 'acrobot':
+        tip = xpos[i, 2] + xmat[i, 2].reshape(3, 3).dot([0, 0, 1.0])
+        dist = np.linalg.norm(np.array([0, 0, 4.0]) - tip)
+        want = task_formulas.acrobot_reward(dist, task == 'swingup_sparse')
+        np.testing.assert_allclose(physics.to_target()[i], dist, rtol=1e-6)
+        np.testing.assert_allclose(
+            ts.observation['orientations'][i],
+            [xmat[i, 1, 2], xmat[i, 2, 2], xmat[i, 1, 8], xmat[i, 2, 8]],
+            atol=1e-6)
       elif domain == 'pendulum':
         want = task_formulas.pendulum_reward(xmat[i, 1, 8])
         np.testing.assert_allclose(ts.observation['orientation'][i],
@@ -459,6 +470,39 @@ def test_get_set_state_copy_round_trip():
     p1.set_state(np.zeros((16, 3)))
   p1.free()
   p2.free()
+
+
+def test_checkpoint_round_trip_continues_bit_for_bit(tmp_path):
+  """save_checkpoint / load_checkpoint (.npz of qpos, qvel, warm start, time):
+  a fresh batch restored from the file continues exactly like the original."""
+  def make():
+    return suite.load('cheetah', 'run', task_kwargs={'random': 3},
+                      environment_kwargs={'batch_size': 96})
+  env = make()
+  env.reset()
+  rs = np.random.RandomState(1)
+  acts = rs.uniform(-1, 1, (30, 96, 6))
+  for a in acts[:12]:
+    env.step(a)
+  path = str(tmp_path/'state.npz')
+  env.physics.save_checkpoint(path)
+  for a in acts[12:]:
+    ts = env.step(a)
+  other = make()
+  other.reset()
+  other.physics.load_checkpoint(path)
+  for a in acts[12:]:
+    ts2 = other.step(a)
+  for k in ts.observation:
+    np.testing.assert_array_equal(ts.observation[k], ts2.observation[k])
+  np.testing.assert_array_equal(ts.reward, ts2.reward)
+  np.testing.assert_array_equal(np.asarray(env.physics.data.time),
+                                np.asarray(other.physics.data.time))
+  small = suite.load('cheetah', 'run', environment_kwargs={'batch_size': 4})
+  with pytest.raises(ValueError):
+    small.physics.load_checkpoint(path)
+  for e in (env, other, small):
+    e.physics.free()
 
 
 def test_c_abi_argument_errors():
