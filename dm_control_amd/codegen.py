@@ -20,7 +20,8 @@ import numpy as np
 from dm_control_amd.mjcf import model as mdl
 
 TASK_NONE, TASK_CARTPOLE, TASK_CHEETAH, TASK_HUMANOID = 0, 1, 2, 3
-TASK_WALKER, TASK_PENDULUM, TASK_ACROBOT = 4, 5, 6
+TASK_WALKER, TASK_PENDULUM, TASK_ACROBOT, TASK_HOPPER = 4, 5, 6, 7
+SENS_TOUCH = 0
 
 _SUPPORTED_PAIRS = {
     (mdl.GEOM_PLANE, mdl.GEOM_SPHERE), (mdl.GEOM_PLANE, mdl.GEOM_CAPSULE),
@@ -136,6 +137,8 @@ def task_bodies(m, task):
     return [m.name2id('pole', 'body')]
   if task == TASK_ACROBOT:
     return [m.name2id('upper_arm', 'body'), m.name2id('lower_arm', 'body')]
+  if task == TASK_HOPPER:
+    return [m.name2id('torso', 'body'), m.name2id('foot', 'body')]
   if task == TASK_HUMANOID:
     return [m.name2id(n, 'body') for n in
             ('torso', 'head', 'left_hand', 'left_foot', 'right_hand',
@@ -156,6 +159,8 @@ def observation_size(m, task):
     return 3
   if task == TASK_ACROBOT:
     return 4 + m.nv
+  if task == TASK_HOPPER:
+    return (m.nq - 1) + m.nv + 2
   return m.nq + m.nv
 
 
@@ -308,6 +313,18 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   tr('pair_solimp', pair_solimp); tr('pair_diag', pair_diag)
   ti('task_body', (task_bodies(m, task) + [0]*6)[:6])
   sites = task_sites(m, task)
+  # touch sensors: spherical zone around a site (mj_sensorAcc, mjSENS_TOUCH)
+  touch = [i for i in range(m.nsensor) if int(m.sensor_type[i]) == SENS_TOUCH]
+  for i in touch:
+    sid = int(m.sensor_objid[i])
+    if getattr(m, 'site_type', None) is not None and int(m.site_type[sid]) != mdl.GEOM_SPHERE:
+      raise UnsupportedModelError('touch sensors need a spherical site')
+  ci('NTOUCH', len(touch))
+  ti('touch_adr', [int(m.sensor_adr[i]) for i in touch])
+  ti('touch_body', [int(m.site_bodyid[int(m.sensor_objid[i])]) for i in touch])
+  tr('touch_pos', [float(v) for i in touch
+                   for v in m.site_pos[int(m.sensor_objid[i])]] or [0, 0, 0])
+  tr('touch_radius', [float(m.site_size[int(m.sensor_objid[i])][0]) for i in touch])
   ti('task_site_body', [s[0] for s in sites] or [0])
   tr('task_site_pos', [v for s in sites for v in s[1]] or [0, 0, 0])
   tr('task_site_size', [s[2] for s in sites] or [0])

@@ -94,7 +94,8 @@ constexpr int GEOM = SEARCH + NVX;
 constexpr int CON = GEOM + NGX*12;
 constexpr int ROWS = CON + NCON_MAX*CCW;
 constexpr int SLV = ROWS + NEFC_MAX*CRW;
-constexpr int OBSV = SLV + NBODY*3;
+constexpr int TOUCH = SLV + NBODY*3;     // touch sensor readings
+constexpr int OBSV = TOUCH + (NTOUCH > 0 ? NTOUCH : 1);
 constexpr int Q0 = OBSV + NOBSX;        // RK4 stage storage
 constexpr int V0 = Q0 + (RK4 ? NQX : 0);
 constexpr int FV = V0 + (RK4 ? NVX : 0);
@@ -281,7 +282,7 @@ DEV void stage_tables() {
 }
 
 struct EnvView {   // the fields task_outputs() reads, as LDS pointers
-  const real *qpos, *qvel, *ctrl, *xpos, *xmat, *subtree_linvel;
+  const real *qpos, *qvel, *ctrl, *xpos, *xmat, *xipos, *subtree_linvel, *touch;
 };
 
 // ---------------------------------------------------------------------------
@@ -1131,6 +1132,41 @@ struct Coop {
     iters = iter;
   }
 
+  // touch sensors (see touch_sensors in dmc_kernels.hip): lane = contact; the
+  // row forces CR_F are those of the final iterate
+  __device__ void touch_sensors() {
+    real acc[NTOUCH > 0 ? NTOUCH : 1];
+    _Pragma("unroll")
+    for (int s = 0; s < NTOUCH; s++) acc[s] = 0;
+    const EnvView V = {S + off::QPOS, S + off::QVEL, S + off::CTRL, S + off::XPOS,
+                       S + off::XMAT, S + off::XIPOS, S + off::SLV, S + off::TOUCH};
+    if (nefc > 0) {
+      for (int c = l; c < ncon; c += G) {
+        const real* rec = S + off::CON + c*CCW;
+        const int r0 = (int)rec[CC_ROW];
+        if (r0 < 0) continue;
+        const int p = (int)rec[CC_PAIR];
+        const int nrow = pair_nrow[p];
+        real fn = 0;
+        for (int j = 0; j < nrow; j++)
+          if (r0 + j < nefc) fn += S[off::ROWS + (r0 + j)*CRW + CR_F];
+        if (!(fn > 0)) continue;
+        real pos[3], normal[3];
+        for (int k = 0; k < 3; k++) { pos[k] = rec[k]; normal[k] = rec[3 + k]; }
+        normalize3(normal);
+        _Pragma("unroll")
+        for (int s = 0; s < NTOUCH; s++)
+          acc[s] += fn*touch_hit(V, s, pos, normal, pair_b1[p], pair_b2[p]);
+      }
+    }
+    _Pragma("unroll")
+    for (int s = 0; s < NTOUCH; s++) {
+      const real total = gsum(acc[s]);
+      if (l == 0) S[off::TOUCH + s] = total;
+    }
+    gsync();
+  }
+
   // forward dynamics at (qpos, qvel, ctrl): qacc, qfrc_smooth, qfrc_constraint
   __device__ void forward(bool actuation, real tol) {
     PROF(PH_EULER);
@@ -1189,6 +1225,7 @@ struct Coop {
       PROF(PH_WARM);
       solve_newton(tol);
     }
+    if (NTOUCH > 0) touch_sensors();
     for (int i = l; i < NV; i += G) S[off::WARM + i] = S[off::QACC + i];
     gsync();
   }
@@ -1328,6 +1365,7 @@ struct Coop {
     }
     time = a.time[e];
     warn = 0; ncon = 0; nefc = 0; iters = 0;
+    if (l < (NTOUCH > 0 ? NTOUCH : 1)) S[off::TOUCH + l] = 0;
   }
   __device__ void store(const DmcArgs& a, int e) {
     const long long n = a.nenv;
@@ -1344,7 +1382,7 @@ struct Coop {
     const long long n = a.nenv;
     if (l == 0) {
       const EnvView V = {S + off::QPOS, S + off::QVEL, S + off::CTRL, S + off::XPOS,
-                         S + off::XMAT, S + off::SLV};
+                         S + off::XMAT, S + off::XIPOS, S + off::SLV, S + off::TOUCH};
       const real rew = task_outputs(V, a, S + off::OBSV);
       a.reward[e] = rew;
       if (accumulate) a.episode_return[e] += rew;
@@ -1363,6 +1401,7 @@ struct Coop {
         else if (ty == 9) a.sensordata[adr*n + e] = S[off::QVEL + jnt_dofadr[o]];
       }
     }
+    if (l < NTOUCH) a.sensordata[touch_adr[l]*n + e] = S[off::TOUCH + l];
     if (a.xpos) for (int i = l; i < NBODY*3; i += G) a.xpos[i*n + e] = S[off::XPOS + i];
     if (a.xmat) for (int i = l; i < NBODY*9; i += G) a.xmat[i*n + e] = S[off::XMAT + i];
   }
@@ -1437,6 +1476,10 @@ dmc_observe(DmcArgs a) {
   C.load(a, e);
   for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[i*n + e];
   gsync();
+  if (NTOUCH > 0 && !(a.flags & 4)) {   // mj_forward, actuation disabled (after_reset)
+    const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
+    if (!C.check_state()) C.forward(false, tol);
+  }
   C.observe_stage();
   if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
     C.ncon = 0; C.nefc = 0;

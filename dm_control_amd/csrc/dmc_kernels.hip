@@ -82,7 +82,7 @@ enum { WARN_INERTIA = 1, WARN_CONTACTFULL = 2, WARN_CNSTRFULL = 4,
        WARN_BADQPOS = 16, WARN_BADQVEL = 32, WARN_BADQACC = 64,
        WARN_BADCTRL = 128 };
 enum { TASK_NONE = 0, TASK_CARTPOLE = 1, TASK_CHEETAH = 2, TASK_HUMANOID = 3,
-       TASK_WALKER = 4, TASK_PENDULUM = 5, TASK_ACROBOT = 6 };
+       TASK_WALKER = 4, TASK_PENDULUM = 5, TASK_ACROBOT = 6, TASK_HOPPER = 7 };
 
 #define DMC_REALPTR real*
 #define DMC_CREALPTR const real*
@@ -282,7 +282,8 @@ struct Env {
   real qM[MAT_REGS], qL[MAT_REGS];   // register-resident only in small mode
   real qfrc_smooth[NVX], qfrc_constraint[NVX], qacc_smooth[NVX], qacc[NVX];
   real subtree_linvel[NBODY*3];
-  int ncon, nefc, iters;
+  real touch[NTOUCH > 0 ? NTOUCH : 1];   // touch sensor readings (mj_sensorAcc)
+  int ncon, nefc, nefc_limit, iters;
   unsigned warn;
 };
 
@@ -1269,6 +1270,72 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
   E.iters = iter;
 }
 
+// ---------------------------------------------------------------------------
+// touch sensors (mjSENS_TOUCH in mj_sensorAcc): sum of the normal forces of the
+// contacts that involve the sensor site's body and whose force ray, cast from
+// the contact point, meets the site's spherical zone
+// ---------------------------------------------------------------------------
+DEV real row_force(const Work& W, int r) {
+  real jar, D;
+  if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS) { jar = W.lrow(r).get(ROW_JAR); D = W.lrow(r).get(ROW_D); }
+  else { jar = W.grow(r).get(ROW_JAR); D = W.grow(r).get(ROW_D); }
+  return jar < 0 ? -D*jar : R(0);
+}
+// smallest t >= 0 with |o + t d| = radius (d unit), or -1
+DEV real ray_sphere(const real* o, const real* d, real radius) {
+  const real b = dot3(o, d), c = dot3(o, o) - radius*radius;
+  const real disc = b*b - c;
+  if (disc < 0) return -1;
+  const real sq = sqrt(disc);
+  if (-b - sq >= 0) return -b - sq;
+  if (-b + sq >= 0) return -b + sq;
+  return -1;
+}
+template <class EnvT>
+DEV real touch_hit(const EnvT& E, int s, const real* pos, const real* normal,
+                   int b1, int b2) {
+  const int body = touch_body[s];
+  if (body != b1 && body != b2) return 0;
+  real o[3], d[3];
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) {
+    const real site = E.xpos[3*body + k] + E.xmat[9*body + 3*k]*R(touch_pos[3*s]) +
+                      E.xmat[9*body + 3*k + 1]*R(touch_pos[3*s + 1]) +
+                      E.xmat[9*body + 3*k + 2]*R(touch_pos[3*s + 2]);
+    o[k] = pos[k] - site;
+    d[k] = body == b2 ? -normal[k] : normal[k];   // ray flips if the sensor is on body 2
+  }
+  return ray_sphere(o, d, R(touch_radius[s])) >= 0 ? R(1) : R(0);
+}
+template <class Rec>
+DEV void touch_of_contact(Env& E, const Work& W, const Rec& rec, int& r) {
+  const int p = (int)rec.get(10);
+  if (rec.get(9) >= pair_includemargin[p]) return;   // contact without rows
+  const int nrow = pair_nrow[p];
+  real fn = 0;
+  for (int j = 0; j < nrow; j++)
+    if (r + j < E.nefc) fn += row_force(W, r + j);
+  r += nrow;
+  if (!(fn > 0)) return;
+  real pos[3], normal[3];
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) { pos[k] = rec.get(k); normal[k] = rec.get(3 + k); }
+  normalize3(normal);
+  DMC_UNROLL
+  for (int s = 0; s < NTOUCH; s++)
+    E.touch[s] += fn*touch_hit(E, s, pos, normal, pair_b1[p], pair_b2[p]);
+}
+DEV void touch_sensors(Env& E, const Work& W) {
+  DMC_UNROLL
+  for (int s = 0; s < NTOUCH; s++) E.touch[s] = 0;
+  if (E.nefc == 0) return;
+  int r = E.nefc_limit;
+  const int n1 = E.ncon < LDS_CONS ? E.ncon : LDS_CONS;
+  for (int k = 0; k < n1; k++) touch_of_contact(E, W, W.lcon(k), r);
+  if (LDS_CONS < NCON_MAX)
+    for (int k = LDS_CONS; k < E.ncon; k++) touch_of_contact(E, W, W.gcon(k), r);
+}
+
 // forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms
 DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
   kinematics(E);
@@ -1278,6 +1345,7 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
   smooth_forces(E, W, actuation);
   E.ncon = 0; E.nefc = 0; E.iters = 0;
   limit_rows(E, W);
+  E.nefc_limit = E.nefc;
 #ifndef DMC_ABLATE_CONTACT
   if (NPAIR > 0) contact_rows(E, W);
 #endif
@@ -1325,6 +1393,7 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     }
     solve_newton(E, W, tol);
   }
+  if (NTOUCH > 0) touch_sensors(E, W);
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.warm[i] = E.qacc[i];
 }
@@ -1601,6 +1670,27 @@ DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
     OBS(2) = E.qvel[0];
     reward = tolerance(E.xmat[9*pole + 8], R(0.9902680687415704), R(1), 0,
                        SIG_GAUSSIAN, R(0.1));
+  } else if (TASK == TASK_HOPPER) {
+    // hopper.py:74-140; task_body = torso, foot; touch sensors toe, heel
+    const int torso = task_body[0], foot = task_body[1];
+    int o = 0;
+    DMC_UNROLL
+    for (int i = 1; i < NQ; i++) OBS(o++) = E.qpos[i];
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) OBS(o++) = E.qvel[i];
+    DMC_UNROLL
+    for (int s = 0; s < NTOUCH; s++) OBS(o++) = log1p(E.touch[s]);
+    const real height = E.xipos[3*torso + 2] - E.xipos[3*foot + 2];
+    const real standing = tolerance(height, R(0.6), R(2), 0, SIG_GAUSSIAN, R(0.1));
+    if (a.task_param_i & 1) {   // hop
+      const real speed = E.subtree_linvel[3*torso];
+      reward = standing*tolerance(speed, 2, inf, 1, SIG_LINEAR, R(0.5));
+    } else {
+      real sc = 0;
+      DMC_UNROLL
+      for (int i = 0; i < NU; i++) sc += tolerance(E.ctrl[i], 0, 0, 1, SIG_QUADRATIC, 0);
+      reward = standing*(sc/NU + 4)/5;
+    }
   } else if (TASK == TASK_ACROBOT) {
     // acrobot.py:62-81,109-126; task_body = upper_arm, lower_arm;
     // task_site = tip (on lower_arm), target (world)
@@ -1645,7 +1735,9 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   DMC_UNROLL
   for (int i = 0; i < NV; i++) { E.qvel[i] = a.qvel[i*n + e]; E.warm[i] = a.warm[i*n + e]; }
   time = a.time[e];
-  E.warn = 0; E.ncon = 0; E.nefc = 0; E.iters = 0;
+  E.warn = 0; E.ncon = 0; E.nefc = 0; E.nefc_limit = 0; E.iters = 0;
+  DMC_UNROLL
+  for (int s = 0; s < (NTOUCH > 0 ? NTOUCH : 1); s++) E.touch[s] = 0;
 }
 DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
   const long long n = a.nenv;
@@ -1702,6 +1794,8 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
     else if (sensor_type[s] == 9)
       a.sensordata[adr*n + e] = E.qvel[jnt_dofadr[o]];
   }
+  DMC_UNROLL
+  for (int t = 0; t < NTOUCH; t++) a.sensordata[touch_adr[t]*n + e] = E.touch[t];
   if (a.xpos) {
     DMC_UNROLL
     for (int i = 0; i < NBODY*3; i++) a.xpos[i*n + e] = E.xpos[i];
@@ -1772,8 +1866,15 @@ dmc_observe(DmcArgs a) {
   const long long n = a.nenv;
   DMC_UNROLL
   for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
-  observe_stage(E, time);
   __shared__ real lds_rows[LDS_WORDS];
+  if (NTOUCH > 0 && !(a.flags & 4)) {
+    // acceleration-stage sensors need the constraint forces: the reference's
+    // after_reset runs mj_forward with actuation disabled (engine.py:283-295)
+    Work W = {lds_rows + threadIdx.x, a.ws + e, n};
+    const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
+    if (!check_state(E, time)) forward(E, W, false, tol);
+  }
+  observe_stage(E, time);
   if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
     Work W = {lds_rows + threadIdx.x, a.ws + e, n};
     E.ncon = 0; E.nefc = 0;
@@ -1835,7 +1936,8 @@ dmc_init_episode(DmcArgs a) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) qvel[i] = R(0.01)*rng.normal();
   } else if (TASK == TASK_CHEETAH || TASK == TASK_HUMANOID ||
-             TASK == TASK_WALKER || TASK == TASK_PENDULUM || TASK == TASK_ACROBOT) {
+             TASK == TASK_WALKER || TASK == TASK_PENDULUM || TASK == TASK_ACROBOT ||
+             TASK == TASK_HOPPER) {
     DMC_UNROLL
     for (int j = 0; j < NJNT; j++) {
       const int qa = jnt_qposadr[j];

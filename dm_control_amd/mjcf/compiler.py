@@ -531,8 +531,14 @@ class _Compiler:
     size = [0.005, 0.005, 0.005]
     for k, v in enumerate(a.get('size', '').split()[:3]):
       size[k] = float(v)
+    kinds = {'sphere': mdl.GEOM_SPHERE, 'capsule': mdl.GEOM_CAPSULE,
+             'ellipsoid': mdl.GEOM_ELLIPSOID, 'cylinder': mdl.GEOM_CYLINDER,
+             'box': mdl.GEOM_BOX}
+    if a.get('type', 'sphere') not in kinds:
+      raise CompileError('unknown site type %r' % a.get('type'))
     self.sites.append(dict(name=a.get('name'), body=body_id, pos=pos,
-                           quat=quat, size=np.array(size)))
+                           quat=quat, size=np.array(size),
+                           type=kinds[a.get('type', 'sphere')]))
 
   # -- assembly -----------------------------------------------------------------
   def compile(self):
@@ -782,6 +788,7 @@ class _Compiler:
     m.site_pos = np.array([s['pos'] for s in self.sites]).reshape(-1, 3)
     m.site_quat = np.array([s['quat'] for s in self.sites]).reshape(-1, 4)
     m.site_size = np.array([s['size'] for s in self.sites]).reshape(-1, 3)
+    m.site_type = np.array([s['type'] for s in self.sites], np.int32)
     self.joints, self.geoms = joints, geoms
 
   def _finish_actuators(self, m):

@@ -4,8 +4,8 @@ Same contract as /root/reference/dm_control/suite/__init__.py:78-150:
 `load(domain_name, task_name, task_kwargs, environment_kwargs,
 visualize_reward)` returns a `control.Environment`; unknown names raise
 ValueError; the tag-derived constants exist.  Domains currently built on the
-HIP path: cartpole, cheetah, humanoid plus walker, pendulum and
-acrobot (first SURVEY.md 8f row); the remaining reference
+HIP path: cartpole, cheetah, humanoid plus walker, pendulum,
+acrobot and hopper (first SURVEY.md 8f row); the remaining reference
 domains need primitives that are not implemented yet.
 
 Batched use: `environment_kwargs={'batch_size': 8192, 'device': 0,
@@ -19,6 +19,7 @@ from dm_control_amd.rl import control
 from dm_control_amd.suite import acrobot
 from dm_control_amd.suite import cartpole
 from dm_control_amd.suite import cheetah
+from dm_control_amd.suite import hopper
 from dm_control_amd.suite import humanoid
 from dm_control_amd.suite import pendulum
 from dm_control_amd.suite import walker

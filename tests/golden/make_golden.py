@@ -120,10 +120,11 @@ def rewards_golden():
 
 
 def tasks_golden():
-  from dm_control.suite import acrobot, cartpole, cheetah, humanoid, pendulum, walker
+  from dm_control.suite import (acrobot, cartpole, cheetah, hopper, humanoid,
+                                pendulum, walker)
   rs = np.random.RandomState(1)
   out = {'cartpole': [], 'cheetah': [], 'humanoid': [], 'walker': [],
-         'pendulum': [], 'acrobot': []}
+         'pendulum': [], 'acrobot': [], 'hopper': []}
 
   for _ in range(24):
     x, cos, ctrl = rs.uniform(-2, 2), rs.uniform(-1, 1), rs.uniform(-1.5, 1.5)
@@ -217,6 +218,21 @@ def tasks_golden():
       rec['obs_keys'] = list(obs.keys())
       rec['obs_orientations'] = np.asarray(obs['orientations']).tolist()
     out['acrobot'].append(rec)
+
+  for _ in range(24):
+    height, speed = rs.uniform(0.1, 2.3), rs.uniform(-1, 4)
+    ctrl, touch = rs.uniform(-1.2, 1.2, 4), rs.uniform(0, 300, 2)*(rs.rand(2) < 0.6)
+
+    class P(hopper.Physics):
+      def height(self): return height
+      def speed(self): return speed
+      def control(self): return ctrl
+    rec = dict(height=height, speed=speed, ctrl=ctrl.tolist(),
+               touch_raw=touch.tolist(), log1p_touch=np.log1p(touch).tolist())
+    for hopping in (False, True):
+      t = hopper.Hopper(hopping=hopping, random=0)
+      rec['reward_hop' if hopping else 'reward_stand'] = float(t.get_reward(P()))
+    out['hopper'].append(rec)
   return out
 
 

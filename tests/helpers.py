@@ -9,10 +9,12 @@ from dm_control_amd.mjcf import compiler
 
 TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
          'humanoid': codegen.TASK_HUMANOID, 'walker': codegen.TASK_WALKER,
-         'pendulum': codegen.TASK_PENDULUM, 'acrobot': codegen.TASK_ACROBOT}
+         'pendulum': codegen.TASK_PENDULUM, 'acrobot': codegen.TASK_ACROBOT,
+         'hopper': codegen.TASK_HOPPER}
 # build mode per suite model (humanoid: see suite/humanoid.py)
 MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'coop',
-         'walker': 'auto', 'pendulum': 'auto', 'acrobot': 'auto'}
+         'walker': 'auto', 'pendulum': 'auto', 'acrobot': 'auto',
+         'hopper': 'auto'}
 
 
 def model_xml(name):
@@ -43,6 +45,13 @@ def initial_states(model, name, nenv, seed):
   elif name == 'pendulum':
     qpos[:, 0] = rs.uniform(-np.pi, np.pi, nenv)
     qvel[:] = rs.randn(nenv, 1)
+  elif name == 'hopper':
+    lim = model.jnt_limited.astype(bool)
+    lo, hi = model.jnt_range[lim].T
+    qpos[:, lim] = rs.uniform(0.3*lo, 0.3*hi, (nenv, lim.sum()))
+    qpos[:, 1] = rs.uniform(-0.16, -0.04, nenv)   # rootz: foot near / into the floor
+    qpos[:, 2] = rs.uniform(-0.2, 0.2, nenv)
+    qvel[:] = 0.5*rs.randn(nenv, model.nv)
   elif name == 'acrobot':
     qpos[:] = rs.uniform(-np.pi, np.pi, (nenv, 2))
     qvel[:] = 2*rs.randn(nenv, 2)
@@ -73,3 +82,34 @@ def rel_err(a, b):
   num = np.max(np.abs(a - b), axis=-1)
   den = np.maximum(1.0, np.max(np.abs(b), axis=-1))
   return num/den
+
+
+def oracle_touch(model, d, sensor_name):
+  """mjSENS_TOUCH from the oracle's contacts and contact forces (call between
+  step2 and step1, when the contact list and the forces belong together):
+  normal forces of contacts on the site's body whose force ray meets the site
+  sphere.  Test-side restatement of mj_sensorAcc's touch case."""
+  i = model.names['sensor'].index(sensor_name)
+  sid = int(model.sensor_objid[i])
+  body = int(model.site_bodyid[sid])
+  centre = d.xpos[body] + d.xmat[body].reshape(3, 3).dot(model.site_pos[sid])
+  radius = model.site_size[sid][0]
+  total = 0.0
+  for c in range(d.ncon):
+    con = d.contact(c)
+    b1 = int(model.geom_bodyid[con['geom1']])
+    b2 = int(model.geom_bodyid[con['geom2']])
+    if body not in (b1, b2):
+      continue
+    fn = d.contact_force(c)[0, 0]
+    if fn <= 0:
+      continue
+    ray = con['frame'][0] * (-1.0 if body == b2 else 1.0)
+    o = con['pos'] - centre
+    b, cc = o.dot(ray), o.dot(o) - radius*radius
+    disc = b*b - cc
+    if disc < 0:
+      continue
+    if -b - np.sqrt(disc) >= 0 or -b + np.sqrt(disc) >= 0:
+      total += fn
+  return total

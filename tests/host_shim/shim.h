@@ -18,5 +18,5 @@ static Dim3 threadIdx, blockIdx;
 static Dim3 blockDim{64, 1, 1};
 static inline void __syncthreads() {}
 using std::sqrt; using std::fabs; using std::pow; using std::exp; using std::log;
-using std::cos; using std::sin; using std::fmax; using std::fmin;
+using std::cos; using std::sin; using std::fmax; using std::fmin; using std::log1p;
 // glibc already declares sincos/sincosf with the signatures the kernel uses

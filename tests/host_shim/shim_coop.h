@@ -24,7 +24,7 @@ static thread_local Dim3 threadIdx;
 static thread_local Dim3 blockIdx;
 static Dim3 blockDim{64, 1, 1};
 using std::sqrt; using std::fabs; using std::pow; using std::exp; using std::log;
-using std::cos; using std::sin; using std::fmax; using std::fmin;
+using std::cos; using std::sin; using std::fmax; using std::fmin; using std::log1p;
 
 struct ShimTeam {
   pthread_barrier_t bar;

@@ -78,3 +78,14 @@ def acrobot_reward(to_target, sparse, target_radius=0.2):
   """suite/acrobot.py:116-126."""
   return rewards.tolerance(to_target, bounds=(0, target_radius),
                            margin=0 if sparse else 1)
+
+
+def hopper_reward(height, speed, ctrl, hopping):
+  """suite/hopper.py:124-140."""
+  standing = rewards.tolerance(height, (0.6, 2))
+  if hopping:
+    return standing*rewards.tolerance(speed, bounds=(2, float('inf')), margin=1,
+                                      value_at_margin=0.5, sigmoid='linear')
+  small_control = rewards.tolerance(np.asarray(ctrl), margin=1, value_at_margin=0,
+                                    sigmoid='quadratic').mean()
+  return standing*(small_control + 4)/5

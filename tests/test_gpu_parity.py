@@ -98,7 +98,8 @@ def _teacher_forced(name, precision, nenv, steps, nsub, lds_budget=None,
 
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
                                        ('humanoid', 5), ('walker', 10),
-                                       ('pendulum', 1), ('acrobot', 1)])
+                                       ('pendulum', 1), ('acrobot', 1),
+                                       ('hopper', 4)])
 def test_fp64_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f64', nenv=64, steps=12, nsub=nsub)
   assert e.max() <= 1e-9, e.max()
@@ -106,7 +107,8 @@ def test_fp64_build_matches_oracle_per_step(name, nsub):
 
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
                                        ('humanoid', 5), ('walker', 10),
-                                       ('pendulum', 1), ('acrobot', 1)])
+                                       ('pendulum', 1), ('acrobot', 1),
+                                       ('hopper', 4)])
 def test_fp32_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f32', nenv=128, steps=12, nsub=nsub)
   assert np.median(e) <= 2e-6, np.median(e)
@@ -116,7 +118,7 @@ def test_fp32_build_matches_oracle_per_step(name, nsub):
 
 @pytest.mark.parametrize('name,nsub,group', [
     ('cartpole', 1, 64), ('cheetah', 1, 64), ('walker', 10, 64),
-    ('cheetah', 1, 32), ('humanoid', 5, 32)])
+    ('hopper', 4, 64), ('cheetah', 1, 32), ('humanoid', 5, 32)])
 def test_several_lanes_per_env_build_matches_oracle(name, nsub, group):
   """csrc/dmc_coop.hip (mode='coop': a group of lanes per env, working set in
   LDS) on models whose default is the one-lane kernel, and with two envs per
@@ -129,6 +131,40 @@ def test_several_lanes_per_env_build_matches_oracle(name, nsub, group):
                       group=group)
   assert np.median(e) <= 2e-6, np.median(e)
   assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
+
+
+@pytest.mark.parametrize('mode', ['unrolled', 'coop'])
+def test_touch_sensors_match_oracle(mode):
+  """mjSENS_TOUCH (hopper toe / heel): the device reading after one physics
+  step against the oracle's contact forces and the same ray-in-zone rule,
+  evaluated between mj_step2 and mj_step1 as mj_sensorAcc does."""
+  model = helpers.load_model('hopper')
+  nenv = 48
+  hm, hb = _device_batch(model, helpers.TASKS['hopper'], 'f64', nenv, mode)
+  qpos, qvel = helpers.initial_states(model, 'hopper', nenv, seed=2)
+  om, datas = _oracle_envs(model, qpos, qvel)
+  rs = np.random.RandomState(0)
+  names = ['touch_toe', 'touch_heel']
+  adr = [int(model.sensor_adr[model.names['sensor'].index(n)]) for n in names]
+  seen = 0
+  for _ in range(30):
+    oq = np.array([d.qpos.copy() for d in datas])
+    ov = np.array([d.qvel.copy() for d in datas])
+    ow = np.array([d.qacc_warmstart.copy() for d in datas])
+    hb.set_state(oq.T, ov.T, ow.T)
+    ctrl = rs.uniform(-1, 1, (nenv, model.nu))
+    hb.step_host(ctrl, 1)
+    got = hb.read(W.FIELD_SENSORDATA).astype(np.float64)
+    for i, d in enumerate(datas):
+      d.ctrl[:] = ctrl[i]
+      d.step2()
+      want = [helpers.oracle_touch(model, d, n) for n in names]
+      d.step1()
+      for k in range(2):
+        np.testing.assert_allclose(got[adr[k], i], want[k], rtol=1e-6, atol=1e-6)
+        seen += want[k] > 0
+  assert seen > 50      # feet were on the floor
+  hb.free()
 
 
 @pytest.mark.parametrize('lds_budget', [64*1024, 36*1024])
@@ -296,7 +332,8 @@ def test_fused_task_outputs_match_reference_formulas():
                              ('walker', 'run', 32), ('walker', 'stand', 32),
                              ('pendulum', 'swingup', 64),
                              ('acrobot', 'swingup', 64),
-                             ('acrobot', 'swingup_sparse', 64)):
+                             ('acrobot', 'swingup_sparse', 64),
+                             ('hopper', 'stand', 32), ('hopper', 'hop', 32)):
     env = suite.load(domain, task, task_kwargs={'random': 4},
                      environment_kwargs={'batch_size': nenv})
     physics = env.physics
@@ -333,6 +370,14 @@ def test_fused_task_outputs_match_reference_formulas():
                                    xmat[i, 1:][:, [0, 2]].ravel(), atol=1e-6)
         np.testing.assert_allclose(ts.observation['height'][i],
                                    xpos[i, torso, 2])
+      elif domain == 'hopper':
+        sens = np.asarray(physics.data.sensordata)[i]
+        want = task_formulas.hopper_reward(physics.height()[i], sens[0], ctrl[i],
+                                           task == 'hop')
+        np.testing.assert_allclose(ts.observation['touch'][i],
+                                   np.log1p(sens[3:5]), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ts.observation['position'][i],
+                                   np.asarray(physics.data.qpos)[i, 1:])
       elif domain == 'acrobot':
         tip = xpos[i, 2] + xmat[i, 2].reshape(3, 3).dot([0, 0, 1.0])
         dist = np.linalg.norm(np.array([0, 0, 4.0]) - tip)

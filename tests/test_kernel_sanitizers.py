@@ -62,6 +62,7 @@ def _run(exe, steps, qpos, qvel):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('name,unroll,extra', [
     ('cheetah', True, ()), ('cheetah', False, ()), ('primitives', True, ()),
+    ('hopper', True, ()),                            # touch sensors
     ('primitives', True, ('-DDMC_BIGMAT=1',)),      # M / Hessian in memory
     ('cheetah', True, ('-DDMC_BIGMAT=1', '-DDMC_LDS_BUDGET=65536'))])   # LDS matrix
 def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path):
@@ -122,7 +123,8 @@ def _build_coop(model, task, tmp_path, sanitizer, group):
     ('humanoid', 'address,undefined', 64, 9),
     ('cheetah', 'thread', 32, 12),
     ('primitives', 'thread', 32, 20),
-    ('cartpole', 'address,undefined', 64, 6)])
+    ('cartpole', 'address,undefined', 64, 6),
+    ('hopper', 'address,undefined', 64, 12)])
 def test_several_lanes_per_env_source(name, sanitizer, group, steps, tmp_path):
   """csrc/dmc_coop.hip with one thread per lane (tests/host_shim/shim_coop.h):
   a phase hand-over is a pthread barrier, so ThreadSanitizer reports any LDS
