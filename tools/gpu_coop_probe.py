@@ -1,7 +1,8 @@
 """Scratch: parity + timing of the several-lanes-per-env build (mode='coop')."""
+import os
 import sys, time
 import numpy as np
-sys.path.insert(0, 'tests')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import helpers
 import test_gpu_parity as T
 from dm_control_amd import suite, wrapper

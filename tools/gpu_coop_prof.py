@@ -1,7 +1,7 @@
 """Scratch: per-phase time of the coop kernel (DMC_COOP_PROFILE build)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, 'tests')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import helpers
 from dm_control_amd import suite, wrapper, build
 name, task, B = sys.argv[1], sys.argv[2], int(sys.argv[3])

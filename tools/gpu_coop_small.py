@@ -1,7 +1,8 @@
 """Scratch: one-lane vs several-lanes-per-env build at small batch sizes."""
+import os
 import sys
 import numpy as np
-sys.path.insert(0, 'tests')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from dm_control_amd import suite, wrapper
 for name, task in [('cheetah', 'run'), ('walker', 'walk'), ('cartpole', 'swingup')]:
   for B in (256, 1024, 2048, 4096, 8192):

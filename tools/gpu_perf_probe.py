@@ -1,7 +1,8 @@
 """Scratch perf probe: per-launch time and solver iteration statistics."""
+import os
 import sys, time
 import numpy as np
-sys.path.insert(0, 'tests')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import helpers
 from dm_control_amd import suite, wrapper
 name, task, B = sys.argv[1], sys.argv[2], int(sys.argv[3])

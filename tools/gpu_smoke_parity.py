@@ -1,7 +1,8 @@
 """Scratch GPU parity probe (not a test): device vs oracle, teacher-forced."""
+import os
 import sys, time
 import numpy as np
-sys.path.insert(0, 'tests')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import helpers
 from dm_control_amd import build, wrapper, codegen
 from oracle import oracle
