@@ -61,6 +61,8 @@ struct dmc_batch {
   hipStream_t own_stream = nullptr;   // created with the batch
   void* field[DMC_FIELD_COUNT] = {};
   size_t bytes[DMC_FIELD_COUNT] = {};
+  size_t rows[DMC_FIELD_COUNT] = {};   // k extent of a [k][nenv] field (1: per-env scalar)
+  size_t elem[DMC_FIELD_COUNT] = {};   // bytes per element
   void* ws = nullptr;
   void* ctrl_staging = nullptr;   // device copy of host-provided controls
   size_t ctrl_staging_bytes = 0;
@@ -95,6 +97,15 @@ int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args, int group = 1) {
   HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, b->stream,
                                 nullptr, config));
   return 0;
+}
+
+// [rows][n] <-> [n][rows] on the host (elements of `elem` bytes): code objects
+// with env-major state keep [nenv][k] in HBM while the ABI presents [k][nenv]
+void transpose_host(const char* src, char* dst, size_t src_rows, size_t src_cols,
+                    size_t elem) {
+  for (size_t r = 0; r < src_rows; r++)
+    for (size_t c = 0; c < src_cols; c++)
+      memcpy(dst + (c*src_rows + r)*elem, src + (r*src_cols + c)*elem, elem);
 }
 
 void fill_args(dmc_batch* b, DmcArgs& a) {
@@ -185,6 +196,7 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   i.ws_per_env = raw[8]; i.task = raw[9]; i.ncon_max = raw[10];
   i.nefc_max = raw[11]; i.integrator = raw[12]; i.npair = raw[13];
   i.lanes_per_env = raw[14] > 0 && raw[14] < 64 ? 64/raw[14] : 1;
+  i.env_major = raw[15] != 0;
   *out = m;
   return 0;
 }
@@ -227,6 +239,11 @@ int dmc_batch_create(const dmc_model* model, int nenv, dmc_batch** out) {
   b->bytes[DMC_FIELD_WARN] = n*sizeof(unsigned);
   b->bytes[DMC_FIELD_STATS] = 3*n*sizeof(int);
   b->bytes[DMC_FIELD_RETURN] = n*rs;
+  for (int f = 0; f < DMC_FIELD_COUNT; f++) {
+    b->elem[f] = (f == DMC_FIELD_WARN || f == DMC_FIELD_STATS) ? sizeof(int) : rs;
+    b->rows[f] = b->bytes[f]/(n*b->elem[f]);
+  }
+  b->rows[DMC_FIELD_OBS] = 1;   // agent layout [nenv][nobs] in every code object
   hipError_t err = hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking);
   b->stream = b->own_stream;
   for (int f = 0; f < DMC_FIELD_COUNT && err == hipSuccess; f++) {
@@ -299,11 +316,20 @@ int dmc_batch_set_state(dmc_batch* b, const void* qpos, const void* qvel,
   struct { const void* src; int f; } items[] = {
       {qpos, DMC_FIELD_QPOS}, {qvel, DMC_FIELD_QVEL},
       {warm, DMC_FIELD_WARMSTART}, {time, DMC_FIELD_TIME}};
-  for (auto& it : items)
-    if (it.src)
-      HIP_TRY(hipMemcpyAsync(b->field[it.f], it.src, b->bytes[it.f],
-                             hipMemcpyHostToDevice, b->stream));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  std::vector<char> tmp;
+  for (auto& it : items) {
+    if (!it.src) continue;
+    const void* src = it.src;
+    if (b->model->info.env_major && b->rows[it.f] > 1) {
+      tmp.resize(b->bytes[it.f]);
+      transpose_host((const char*)it.src, tmp.data(), b->rows[it.f],
+                     (size_t)b->nenv, b->elem[it.f]);
+      src = tmp.data();
+    }
+    HIP_TRY(hipMemcpyAsync(b->field[it.f], src, b->bytes[it.f],
+                           hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));   // `tmp` is reused
+  }
   return 0;
 }
 
@@ -376,9 +402,14 @@ int dmc_batch_read(dmc_batch* b, int field, void* dst, size_t bytes) {
     return fail("dmc_batch_read: field %d has %zu bytes, caller asked for %zu",
                 field, b->bytes[field], bytes);
   HIP_TRY(hipSetDevice(b->model->device));
-  HIP_TRY(hipMemcpyAsync(dst, b->field[field], bytes, hipMemcpyDeviceToHost,
-                         b->stream));
+  const bool flip = b->model->info.env_major && b->rows[field] > 1;
+  std::vector<char> tmp(flip ? bytes : 0);
+  HIP_TRY(hipMemcpyAsync(flip ? (void*)tmp.data() : dst, b->field[field], bytes,
+                         hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
+  if (flip)
+    transpose_host(tmp.data(), (char*)dst, (size_t)b->nenv, b->rows[field],
+                   b->elem[field]);
   return 0;
 }
 
@@ -398,7 +429,8 @@ int dmc_batch_clear_warnings(dmc_batch* b) {
 int dmc_batch_copy_state(dmc_batch* dst, const dmc_batch* src) {
   if (!dst || !src) return fail("null batch");
   if (dst->nenv != src->nenv || dst->model->info.nq != src->model->info.nq ||
-      dst->model->info.real_size != src->model->info.real_size)
+      dst->model->info.real_size != src->model->info.real_size ||
+      dst->model->info.env_major != src->model->info.env_major)
     return fail("dmc_batch_copy_state: incompatible batches");
   HIP_TRY(hipSetDevice(dst->model->device));
   HIP_TRY(hipStreamSynchronize(src->stream));

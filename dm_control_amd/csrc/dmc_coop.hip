@@ -40,10 +40,10 @@ static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group must divide a wave
 constexpr int RNV = (NVX + G - 1)/G;    // lane rounds needed to cover the dofs
 
 constexpr int odd_(int x) { return x | 1; }
-constexpr int NQX = NQ > 0 ? NQ : 1;
 constexpr int NJX = NJNT > 0 ? NJNT : 1;
 constexpr int NGX = NGEOM > 0 ? NGEOM : 1;
 constexpr int NOBSX = NOBS > 0 ? NOBS : 1;
+constexpr int NSDX = NSENSORDATA > 0 ? NSENSORDATA : 1;
 constexpr int NVP = odd_(NVX);          // row stride of M and H (odd: lane = row is conflict-free)
 // constraint row record: J(nv), D, aref, Jaref, Jv, force
 enum { CR_D = NV, CR_AREF = NV + 1, CR_JAR = NV + 2, CR_JV = NV + 3, CR_F = NV + 4 };
@@ -1359,9 +1359,9 @@ struct Coop {
   // ---- HBM I/O ---------------------------------------------------------------
   __device__ void load(const DmcArgs& a, int e) {
     const long long n = a.nenv;
-    for (int i = l; i < NQ; i += G) S[off::QPOS + i] = a.qpos[i*n + e];
+    for (int i = l; i < NQ; i += G) S[off::QPOS + i] = a.qpos[sidx(i, e, n, NQX)];
     for (int i = l; i < NV; i += G) {
-      S[off::QVEL + i] = a.qvel[i*n + e]; S[off::WARM + i] = a.warm[i*n + e];
+      S[off::QVEL + i] = a.qvel[sidx(i, e, n, NVX)]; S[off::WARM + i] = a.warm[sidx(i, e, n, NVX)];
     }
     time = a.time[e];
     warn = 0; ncon = 0; nefc = 0; iters = 0;
@@ -1369,9 +1369,9 @@ struct Coop {
   }
   __device__ void store(const DmcArgs& a, int e) {
     const long long n = a.nenv;
-    for (int i = l; i < NQ; i += G) a.qpos[i*n + e] = S[off::QPOS + i];
+    for (int i = l; i < NQ; i += G) a.qpos[sidx(i, e, n, NQX)] = S[off::QPOS + i];
     for (int i = l; i < NV; i += G) {
-      a.qvel[i*n + e] = S[off::QVEL + i]; a.warm[i*n + e] = S[off::WARM + i];
+      a.qvel[sidx(i, e, n, NVX)] = S[off::QVEL + i]; a.warm[sidx(i, e, n, NVX)] = S[off::WARM + i];
     }
     if (l == 0) {
       a.time[e] = time;
@@ -1386,7 +1386,8 @@ struct Coop {
       const real rew = task_outputs(V, a, S + off::OBSV);
       a.reward[e] = rew;
       if (accumulate) a.episode_return[e] += rew;
-      a.stats[e] = ncon; a.stats[n + e] = nefc; a.stats[2*n + e] = iters;
+      a.stats[sidx(0, e, n, 3)] = ncon; a.stats[sidx(1, e, n, 3)] = nefc;
+      a.stats[sidx(2, e, n, 3)] = iters;
     }
     gsync();
     for (int k = l; k < NOBS; k += G)
@@ -1395,15 +1396,15 @@ struct Coop {
       const int adr = sensor_adr[s], o = sensor_objid[s], ty = sensor_type[s];
       if (ty == 35 || ty == 34) {
         const int src = ty == 35 ? off::SLV : off::SUBCOM;
-        if (l < 3) a.sensordata[(adr + l)*n + e] = S[src + 3*o + l];
+        if (l < 3) a.sensordata[sidx(adr + l, e, n, NSDX)] = S[src + 3*o + l];
       } else if (l == 0) {
-        if (ty == 8) a.sensordata[adr*n + e] = S[off::QPOS + jnt_qposadr[o]];
-        else if (ty == 9) a.sensordata[adr*n + e] = S[off::QVEL + jnt_dofadr[o]];
+        if (ty == 8) a.sensordata[sidx(adr, e, n, NSDX)] = S[off::QPOS + jnt_qposadr[o]];
+        else if (ty == 9) a.sensordata[sidx(adr, e, n, NSDX)] = S[off::QVEL + jnt_dofadr[o]];
       }
     }
-    if (l < NTOUCH) a.sensordata[touch_adr[l]*n + e] = S[off::TOUCH + l];
-    if (a.xpos) for (int i = l; i < NBODY*3; i += G) a.xpos[i*n + e] = S[off::XPOS + i];
-    if (a.xmat) for (int i = l; i < NBODY*9; i += G) a.xmat[i*n + e] = S[off::XMAT + i];
+    if (l < NTOUCH) a.sensordata[sidx(touch_adr[l], e, n, NSDX)] = S[off::TOUCH + l];
+    if (a.xpos) for (int i = l; i < NBODY*3; i += G) a.xpos[sidx(i, e, n, NBODY*3)] = S[off::XPOS + i];
+    if (a.xmat) for (int i = l; i < NBODY*9; i += G) a.xmat[sidx(i, e, n, NBODY*9)] = S[off::XMAT + i];
   }
 };
 
@@ -1434,9 +1435,9 @@ dmc_step(DmcArgs a) {
       C.warn |= WARN_BADCTRL;
       for (int i = l; i < NU; i += G) S[off::CTRL + i] = 0;
     }
-    for (int i = l; i < NU; i += G) a.ctrl_store[i*n + e] = S[off::CTRL + i];
+    for (int i = l; i < NU; i += G) a.ctrl_store[sidx(i, e, n, NUX)] = S[off::CTRL + i];
   } else {
-    for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[i*n + e];
+    for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[sidx(i, e, n, NUX)];
   }
   gsync();
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
@@ -1448,7 +1449,7 @@ dmc_step(DmcArgs a) {
 #ifdef DMC_COOP_PROFILE
   { const long long t_ = wall_clock64(); C.tprof[PH_EULER] += t_ - C.tlast; C.tlast = t_; }
 #endif
-  if (a.qacc) for (int i = l; i < NV; i += G) a.qacc[i*n + e] = S[off::QACC + i];
+  if (a.qacc) for (int i = l; i < NV; i += G) a.qacc[sidx(i, e, n, NVX)] = S[off::QACC + i];
   if (!(a.flags & 2)) {
     C.observe_stage();
     C.outputs(a, e, true);
@@ -1474,7 +1475,7 @@ dmc_observe(DmcArgs a) {
   real* S = C.S;
   const long long n = a.nenv;
   C.load(a, e);
-  for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[i*n + e];
+  for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[sidx(i, e, n, NUX)];
   gsync();
   if (NTOUCH > 0 && !(a.flags & 4)) {   // mj_forward, actuation disabled (after_reset)
     const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
@@ -1492,4 +1493,5 @@ dmc_observe(DmcArgs a) {
 extern "C" __device__ const int dmc_info[16] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     1 /*workspace reals per env: none, everything is in LDS*/, TASK, NCON_MAX, NEFC_MAX,
-    INTEGRATOR, NPAIR, EPB /*envs per 64-lane workgroup*/, G};
+    INTEGRATOR, NPAIR, EPB /*envs per 64-lane workgroup*/,
+    DMC_ENV_MAJOR /*state fields are [env][k]*/};

@@ -70,6 +70,7 @@ constexpr bool BIGMAT = DMC_BIGMAT != 0 && NM > 0;
 constexpr int MAT_REGS = BIGMAT ? 1 : (NM > 0 ? NM : 1);
 constexpr int NVX = NV > 0 ? NV : 1;
 constexpr int NUX = NU > 0 ? NU : 1;
+constexpr int NQX = NQ > 0 ? NQ : 1;
 constexpr real MAXVAL = R(1e10);
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
@@ -87,6 +88,21 @@ enum { TASK_NONE = 0, TASK_CARTPOLE = 1, TASK_CHEETAH = 2, TASK_HUMANOID = 3,
 #define DMC_REALPTR real*
 #define DMC_CREALPTR const real*
 #include "dmc_args.h"
+
+// Layout of the 2-D state fields in HBM.  One env per lane: [k][env], so a
+// wave's loads are unit-stride over envs.  One env per group of lanes
+// (dmc_coop.hip): [env][k], so a group's loads are unit-stride over k -- with
+// [k][env] it would touch one 32-byte sector per word (measured: 47 MB moved
+// per humanoid launch for 8 MB of state).  The C ABI presents [k][env] either
+// way (dmc_api.cpp transposes on the host side of read / set_state).
+#ifdef DMC_COOP_BUILD
+#define DMC_ENV_MAJOR 1
+#else
+#define DMC_ENV_MAJOR 0
+#endif
+static __device__ __forceinline__ long long sidx(int k, long long e, long long n, int K) {
+  return DMC_ENV_MAJOR ? e*K + k : k*n + e;
+}
 
 // ---------------------------------------------------------------------------
 // math helpers
@@ -1913,7 +1929,7 @@ dmc_init_episode(DmcArgs a) {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= a.nenv) return;
   const long long n = a.nenv;
-  if ((a.flags & 8) && a.stats[e] == 0) return;
+  if ((a.flags & 8) && a.stats[sidx(0, e, n, 3)] == 0) return;
   Rng rng = {a.seed*0x2545F4914F6CDD1DULL + (uint64_t)e, 0};
   real qpos[NQ > 0 ? NQ : 1], qvel[NVX];
   DMC_UNROLL
@@ -1959,11 +1975,11 @@ dmc_init_episode(DmcArgs a) {
     }
   }
   DMC_UNROLL
-  for (int i = 0; i < NQ; i++) a.qpos[i*n + e] = qpos[i];
+  for (int i = 0; i < NQ; i++) a.qpos[sidx(i, e, n, NQX)] = qpos[i];
   DMC_UNROLL
-  for (int i = 0; i < NV; i++) { a.qvel[i*n + e] = qvel[i]; a.warm[i*n + e] = 0; }
+  for (int i = 0; i < NV; i++) { a.qvel[sidx(i, e, n, NVX)] = qvel[i]; a.warm[sidx(i, e, n, NVX)] = 0; }
   DMC_UNROLL
-  for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = 0;
+  for (int i = 0; i < NU; i++) a.ctrl_store[sidx(i, e, n, NUX)] = 0;
   a.time[e] = 0;
   a.episode_return[e] = 0;
 }
@@ -1973,5 +1989,6 @@ dmc_init_episode(DmcArgs a) {
 extern "C" __device__ const int dmc_info[16] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     (WS_WORDS > 0 ? WS_WORDS : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
-    INTEGRATOR, NPAIR, 64 /*envs per 64-lane workgroup of dmc_step/dmc_observe*/, 0};
+    INTEGRATOR, NPAIR, 64 /*envs per 64-lane workgroup of dmc_step/dmc_observe*/,
+    DMC_ENV_MAJOR /*0: state fields are [k][env]*/};
 #endif

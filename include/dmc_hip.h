@@ -74,7 +74,10 @@ enum dmc_warn_bit {
 typedef struct dmc_model_info {
   int abi, real_size, nq, nv, nu, nbody, nobs, nsensordata, ws_per_env, task,
       ncon_max, nefc_max, integrator, npair,
-      lanes_per_env; /* 1, or the group size of a several-lanes-per-env build */
+      lanes_per_env, /* 1, or the group size of a several-lanes-per-env build */
+      env_major;     /* 1: the 2-D state fields are [nenv][k] in HBM (what
+                        dmc_batch_device_ptr returns); dmc_batch_read and
+                        dmc_batch_set_state present [k][nenv] regardless */
 } dmc_model_info;
 
 int dmc_version(void);

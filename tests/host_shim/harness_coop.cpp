@@ -28,11 +28,12 @@ int main(int argc, char** argv) {
   std::vector<int> stats(3*n, 0);
   // initial states from argv: per env qpos then qvel
   int at = 3;
+  // several-lanes-per-env code objects keep the state env-major: [env][k]
   for (int e = 0; e < n; e++) {
     for (int i = 0; i < NQ; i++)
-      qpos[i*n + e] = at < argc ? (real)atof(argv[at++]) : (real)qpos0[i];
+      qpos[e*nq + i] = at < argc ? (real)atof(argv[at++]) : (real)qpos0[i];
     for (int i = 0; i < NV; i++)
-      qvel[i*n + e] = at < argc ? (real)atof(argv[at++]) : (real)0;
+      qvel[e*nv + i] = at < argc ? (real)atof(argv[at++]) : (real)0;
   }
   DmcArgs& a = g_args;
   memset(&a, 0, sizeof a);
@@ -50,9 +51,9 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 64; i++) pthread_join(th[i], nullptr);
     for (int e = 0; e < n; e++) {
       printf("STEP %d %d", t, e);
-      for (int i = 0; i < NQ; i++) printf(" %.17g", (double)qpos[i*n + e]);
-      for (int i = 0; i < NV; i++) printf(" %.17g", (double)qvel[i*n + e]);
-      printf(" | %d %d %d %u\n", stats[e], stats[n + e], stats[2*n + e], warn[e]);
+      for (int i = 0; i < NQ; i++) printf(" %.17g", (double)qpos[e*nq + i]);
+      for (int i = 0; i < NV; i++) printf(" %.17g", (double)qvel[e*nv + i]);
+      printf(" | %d %d %d %u\n", stats[3*e], stats[3*e + 1], stats[3*e + 2], warn[e]);
     }
   }
   return 0;
