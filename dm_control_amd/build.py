@@ -98,7 +98,16 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
   # -fno-hip-fp32-correctly-rounded-divide-sqrt (fp32 build only): v_rcp/v_rsq
   #   based division and sqrt (<= 2.5 ulp) instead of the 10-instruction
   #   IEEE sequences; the fp64 build keeps exact division.
+  # -ffinite-math-only -fno-signed-zeros: lets LLVM fold 0*x and x+0.  In the
+  #   unrolled build the world frame, joint axes and body offsets are
+  #   constants, so for the planar suite models (cheetah, walker, hopper,
+  #   cart-pole, ...) the y components, two quaternion entries and four matrix
+  #   entries of every frame are exact zeros that now disappear at compile time
+  #   (cheetah: 25.4 k -> 18.6 k VALU instructions per step).  Values are
+  #   unchanged for finite inputs; NaN/inf detection is done on bit patterns
+  #   (`bad()` in the kernel source), not with comparisons.
   cmd = [_hipcc(), '--genco', '--offload-arch=' + ARCH, '-O3', '-std=c++17',
+         '-ffinite-math-only', '-fno-signed-zeros',
          '-Rpass-analysis=kernel-resource-usage',
          '-mllvm', '-pragma-unroll-threshold=%s' % os.environ.get(
              'DMC_PRAGMA_UNROLL_THRESHOLD', '10000000'), '-fno-slp-vectorize',

@@ -171,7 +171,23 @@ DEV void quat_integrate(real* q, const real* w, real h) {
   q[0] = r[0]; q[1] = r[1]; q[2] = r[2]; q[3] = r[3];
 }
 DEV real clampr(real x, real lo, real hi) { return x < lo ? lo : (x > hi ? hi : x); }
+// |x| > MAXVAL, +-inf or NaN, decided on the bit pattern: the build uses
+// -ffinite-math-only (so that the structural zeros of planar models fold away),
+// under which a floating-point comparison may not be relied on to catch NaN.
+// For IEEE numbers the magnitude bits order like the magnitudes, and every
+// inf / NaN pattern lies above every finite one.
+#ifdef DMC_HOST_SHIM
 DEV bool bad(real x) { return !(x <= MAXVAL && x >= -MAXVAL); }
+#elif defined(DMC_REAL_IS_DOUBLE)
+DEV bool bad(double x) {
+  return ((unsigned long long)__double_as_longlong(x) & 0x7fffffffffffffffULL) >
+         (unsigned long long)__double_as_longlong(1e10);
+}
+#else
+DEV bool bad(float x) {
+  return ((unsigned)__float_as_int(x) & 0x7fffffffu) > (unsigned)__float_as_int(1e10f);
+}
+#endif
 
 // spatial vectors [angular, linear] about the subtree-root centre of mass
 DEV void cross_motion(real* r, const real* v, const real* s) {
