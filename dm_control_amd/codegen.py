@@ -21,6 +21,7 @@ from dm_control_amd.mjcf import model as mdl
 
 TASK_NONE, TASK_CARTPOLE, TASK_CHEETAH, TASK_HUMANOID = 0, 1, 2, 3
 TASK_WALKER, TASK_PENDULUM, TASK_ACROBOT, TASK_HOPPER = 4, 5, 6, 7
+TASK_REACHER = 8
 SENS_TOUCH = 0
 
 _SUPPORTED_PAIRS = {
@@ -139,6 +140,8 @@ def task_bodies(m, task):
     return [m.name2id('upper_arm', 'body'), m.name2id('lower_arm', 'body')]
   if task == TASK_HOPPER:
     return [m.name2id('torso', 'body'), m.name2id('foot', 'body')]
+  if task == TASK_REACHER:
+    return [m.name2id('finger', 'body')]
   if task == TASK_HUMANOID:
     return [m.name2id(n, 'body') for n in
             ('torso', 'head', 'left_hand', 'left_foot', 'right_hand',
@@ -161,17 +164,30 @@ def observation_size(m, task):
     return 4 + m.nv
   if task == TASK_HOPPER:
     return (m.nq - 1) + m.nv + 2
+  if task == TASK_REACHER:
+    return m.nq + 2 + m.nv
   return m.nq + m.nv
+
+
+def task_data_size(task):
+  """Per-instance task parameters (DMC_FIELD_TASKDATA rows)."""
+  return {TASK_REACHER: 2}.get(task, 0)     # reacher: target x, y
 
 
 def task_sites(m, task):
   """Sites a task's reward reads: [(body id, local pos[3], size[0])]."""
-  names = {TASK_ACROBOT: ('tip', 'target')}.get(task, ())
+  names = {TASK_ACROBOT: ('tip', 'target'),
+           TASK_REACHER: ('geom:finger', 'geom:target')}.get(task, ())
   out = []
   for n in names:
-    i = m.name2id(n, 'site')
-    out.append((int(m.site_bodyid[i]), [float(v) for v in m.site_pos[i]],
-                float(m.site_size[i][0])))
+    if n.startswith('geom:'):     # a geom frame used like a site
+      i = m.name2id(n[5:], 'geom')
+      out.append((int(m.geom_bodyid[i]), [float(v) for v in m.geom_pos[i]],
+                  float(m.geom_size[i][0])))
+    else:
+      i = m.name2id(n, 'site')
+      out.append((int(m.site_bodyid[i]), [float(v) for v in m.site_pos[i]],
+                  float(m.site_size[i][0])))
   return out
 
 
@@ -282,6 +298,7 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   ci('NPAIR', len(pairs)); ci('NCON_MAX', ncon_max); ci('NEFC_MAX', nefc_max)
   ci('NLIMIT', len(limit_jnt)); ci('TASK', task)
   ci('NOBS', observation_size(m, task))
+  ci('NTASKDATA', task_data_size(task))
   cd('timestep', dt); cd('tolerance_opt', m.opt.tolerance)
   cd('meaninertia', m.meaninertia)
   tr('gravity', m.opt.gravity)

@@ -124,6 +124,7 @@ void fill_args(dmc_batch* b, DmcArgs& a) {
   a.obs_se = b->model->info.nobs;
   a.reward = b->field[DMC_FIELD_REWARD];
   a.episode_return = b->field[DMC_FIELD_RETURN];
+  a.taskdata = b->field[DMC_FIELD_TASKDATA];
   a.sensordata = b->field[DMC_FIELD_SENSORDATA];
   a.xpos = b->aux_outputs ? b->field[DMC_FIELD_XPOS] : nullptr;
   a.xmat = b->aux_outputs ? b->field[DMC_FIELD_XMAT] : nullptr;
@@ -182,7 +183,7 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   hipDeviceptr_t dptr = nullptr;
   size_t bytes = 0;
   err = hipModuleGetGlobal(&dptr, &bytes, m->module, "dmc_info");
-  int raw[16] = {0};
+  int raw[20] = {0};
   if (err == hipSuccess && bytes >= sizeof raw)
     err = hipMemcpy(raw, dptr, sizeof raw, hipMemcpyDeviceToHost);
   if (err != hipSuccess || raw[0] != 1) {
@@ -197,6 +198,7 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   i.nefc_max = raw[11]; i.integrator = raw[12]; i.npair = raw[13];
   i.lanes_per_env = raw[14] > 0 && raw[14] < 64 ? 64/raw[14] : 1;
   i.env_major = raw[15] != 0;
+  i.ntaskdata = raw[16];
   *out = m;
   return 0;
 }
@@ -239,6 +241,7 @@ int dmc_batch_create(const dmc_model* model, int nenv, dmc_batch** out) {
   b->bytes[DMC_FIELD_WARN] = n*sizeof(unsigned);
   b->bytes[DMC_FIELD_STATS] = 3*n*sizeof(int);
   b->bytes[DMC_FIELD_RETURN] = n*rs;
+  b->bytes[DMC_FIELD_TASKDATA] = atleast1(i.ntaskdata)*n*rs;
   for (int f = 0; f < DMC_FIELD_COUNT; f++) {
     b->elem[f] = (f == DMC_FIELD_WARN || f == DMC_FIELD_STATS) ? sizeof(int) : rs;
     b->rows[f] = b->bytes[f]/(n*b->elem[f]);
@@ -330,6 +333,29 @@ int dmc_batch_set_state(dmc_batch* b, const void* qpos, const void* qvel,
                            hipMemcpyHostToDevice, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));   // `tmp` is reused
   }
+  return 0;
+}
+
+int dmc_batch_write(dmc_batch* b, int field, const void* src, size_t bytes) {
+  if (!b || !src) return fail("dmc_batch_write: null argument");
+  if (field != DMC_FIELD_QPOS && field != DMC_FIELD_QVEL &&
+      field != DMC_FIELD_WARMSTART && field != DMC_FIELD_TIME &&
+      field != DMC_FIELD_TASKDATA)
+    return fail("dmc_batch_write: field %d is not writable", field);
+  if (bytes != b->bytes[field])
+    return fail("dmc_batch_write: field %d has %zu bytes, caller passed %zu",
+                field, b->bytes[field], bytes);
+  HIP_TRY(hipSetDevice(b->model->device));
+  std::vector<char> tmp;
+  if (b->model->info.env_major && b->rows[field] > 1) {
+    tmp.resize(bytes);
+    transpose_host((const char*)src, tmp.data(), b->rows[field], (size_t)b->nenv,
+                   b->elem[field]);
+    src = tmp.data();
+  }
+  HIP_TRY(hipMemcpyAsync(b->field[field], src, bytes, hipMemcpyHostToDevice,
+                         b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
 

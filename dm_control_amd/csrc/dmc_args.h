@@ -28,6 +28,7 @@ struct DmcArgs {
   unsigned* warn;          // [nenv] sticky mjtWarning bit mask
   int* stats;              // [3][nenv]: ncon, nefc, solver iterations
   DMC_REALPTR ws;          // workspace, ws_per_env reals per env, [idx][nenv]
+  DMC_REALPTR taskdata;    // [NTASKDATA][nenv] per-instance task parameters
   double task_param_r[4];
 };
 // dmc_step flags

@@ -95,7 +95,8 @@ constexpr int CON = GEOM + NGX*12;
 constexpr int ROWS = CON + NCON_MAX*CCW;
 constexpr int SLV = ROWS + NEFC_MAX*CRW;
 constexpr int TOUCH = SLV + NBODY*3;     // touch sensor readings
-constexpr int OBSV = TOUCH + (NTOUCH > 0 ? NTOUCH : 1);
+constexpr int TASKD = TOUCH + (NTOUCH > 0 ? NTOUCH : 1);   // per-instance task parameters
+constexpr int OBSV = TASKD + NTDX;
 constexpr int Q0 = OBSV + NOBSX;        // RK4 stage storage
 constexpr int V0 = Q0 + (RK4 ? NQX : 0);
 constexpr int FV = V0 + (RK4 ? NVX : 0);
@@ -282,7 +283,8 @@ DEV void stage_tables() {
 }
 
 struct EnvView {   // the fields task_outputs() reads, as LDS pointers
-  const real *qpos, *qvel, *ctrl, *xpos, *xmat, *xipos, *subtree_linvel, *touch;
+  const real *qpos, *qvel, *ctrl, *xpos, *xmat, *xipos, *subtree_linvel, *touch,
+             *taskdata;
 };
 
 // ---------------------------------------------------------------------------
@@ -1139,7 +1141,8 @@ struct Coop {
     _Pragma("unroll")
     for (int s = 0; s < NTOUCH; s++) acc[s] = 0;
     const EnvView V = {S + off::QPOS, S + off::QVEL, S + off::CTRL, S + off::XPOS,
-                       S + off::XMAT, S + off::XIPOS, S + off::SLV, S + off::TOUCH};
+                       S + off::XMAT, S + off::XIPOS, S + off::SLV, S + off::TOUCH,
+                         S + off::TASKD};
     if (nefc > 0) {
       for (int c = l; c < ncon; c += G) {
         const real* rec = S + off::CON + c*CCW;
@@ -1366,6 +1369,7 @@ struct Coop {
     time = a.time[e];
     warn = 0; ncon = 0; nefc = 0; iters = 0;
     if (l < (NTOUCH > 0 ? NTOUCH : 1)) S[off::TOUCH + l] = 0;
+    for (int i = l; i < NTASKDATA; i += G) S[off::TASKD + i] = a.taskdata[sidx(i, e, n, NTDX)];
   }
   __device__ void store(const DmcArgs& a, int e) {
     const long long n = a.nenv;
@@ -1382,7 +1386,8 @@ struct Coop {
     const long long n = a.nenv;
     if (l == 0) {
       const EnvView V = {S + off::QPOS, S + off::QVEL, S + off::CTRL, S + off::XPOS,
-                         S + off::XMAT, S + off::XIPOS, S + off::SLV, S + off::TOUCH};
+                         S + off::XMAT, S + off::XIPOS, S + off::SLV, S + off::TOUCH,
+                         S + off::TASKD};
       const real rew = task_outputs(V, a, S + off::OBSV);
       a.reward[e] = rew;
       if (accumulate) a.episode_return[e] += rew;
@@ -1490,8 +1495,8 @@ dmc_observe(DmcArgs a) {
   C.store(a, e);
 }
 
-extern "C" __device__ const int dmc_info[16] = {
+extern "C" __device__ const int dmc_info[20] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     1 /*workspace reals per env: none, everything is in LDS*/, TASK, NCON_MAX, NEFC_MAX,
     INTEGRATOR, NPAIR, EPB /*envs per 64-lane workgroup*/,
-    DMC_ENV_MAJOR /*state fields are [env][k]*/};
+    DMC_ENV_MAJOR /*state fields are [env][k]*/, NTASKDATA, 0, 0, 0};

@@ -71,6 +71,7 @@ constexpr int MAT_REGS = BIGMAT ? 1 : (NM > 0 ? NM : 1);
 constexpr int NVX = NV > 0 ? NV : 1;
 constexpr int NUX = NU > 0 ? NU : 1;
 constexpr int NQX = NQ > 0 ? NQ : 1;
+constexpr int NTDX = NTASKDATA > 0 ? NTASKDATA : 1;
 constexpr real MAXVAL = R(1e10);
 
 enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
@@ -83,7 +84,8 @@ enum { WARN_INERTIA = 1, WARN_CONTACTFULL = 2, WARN_CNSTRFULL = 4,
        WARN_BADQPOS = 16, WARN_BADQVEL = 32, WARN_BADQACC = 64,
        WARN_BADCTRL = 128 };
 enum { TASK_NONE = 0, TASK_CARTPOLE = 1, TASK_CHEETAH = 2, TASK_HUMANOID = 3,
-       TASK_WALKER = 4, TASK_PENDULUM = 5, TASK_ACROBOT = 6, TASK_HOPPER = 7 };
+       TASK_WALKER = 4, TASK_PENDULUM = 5, TASK_ACROBOT = 6, TASK_HOPPER = 7,
+       TASK_REACHER = 8 };
 
 #define DMC_REALPTR real*
 #define DMC_CREALPTR const real*
@@ -315,6 +317,7 @@ struct Env {
   real qfrc_smooth[NVX], qfrc_constraint[NVX], qacc_smooth[NVX], qacc[NVX];
   real subtree_linvel[NBODY*3];
   real touch[NTOUCH > 0 ? NTOUCH : 1];   // touch sensor readings (mj_sensorAcc)
+  real taskdata[NTDX];                   // per-instance task parameters
   int ncon, nefc, nefc_limit, iters;
   unsigned warn;
 };
@@ -1723,6 +1726,27 @@ DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
       for (int i = 0; i < NU; i++) sc += tolerance(E.ctrl[i], 0, 0, 1, SIG_QUADRATIC, 0);
       reward = standing*(sc/NU + 4)/5;
     }
+  } else if (TASK == TASK_REACHER) {
+    // reacher.py:64-122; task_body = finger; task_site = finger geom, target
+    // geom; the target's x, y are per-instance data (the reference rewrites
+    // model.geom_pos each episode), task_param_r[0] = target + finger radius
+    const int finger = task_site_body[0];
+    real to[2];
+    DMC_UNROLL
+    for (int k = 0; k < 2; k++) {
+      const real f = E.xpos[3*finger + k] + E.xmat[9*finger + 3*k]*R(task_site_pos[0]) +
+                     E.xmat[9*finger + 3*k + 1]*R(task_site_pos[1]) +
+                     E.xmat[9*finger + 3*k + 2]*R(task_site_pos[2]);
+      to[k] = E.taskdata[k] - f;
+    }
+    int o = 0;
+    DMC_UNROLL
+    for (int i = 0; i < NQ; i++) OBS(o++) = E.qpos[i];
+    OBS(o++) = to[0]; OBS(o++) = to[1];
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) OBS(o++) = E.qvel[i];
+    reward = tolerance(sqrt(to[0]*to[0] + to[1]*to[1]), 0, R(a.task_param_r[0]), 0,
+                       SIG_GAUSSIAN, R(0.1));
   } else if (TASK == TASK_ACROBOT) {
     // acrobot.py:62-81,109-126; task_body = upper_arm, lower_arm;
     // task_site = tip (on lower_arm), target (world)
@@ -1767,6 +1791,8 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   DMC_UNROLL
   for (int i = 0; i < NV; i++) { E.qvel[i] = a.qvel[i*n + e]; E.warm[i] = a.warm[i*n + e]; }
   time = a.time[e];
+  DMC_UNROLL
+  for (int i = 0; i < NTASKDATA; i++) E.taskdata[i] = a.taskdata[sidx(i, e, n, NTDX)];
   E.warn = 0; E.ncon = 0; E.nefc = 0; E.nefc_limit = 0; E.iters = 0;
   DMC_UNROLL
   for (int s = 0; s < (NTOUCH > 0 ? NTOUCH : 1); s++) E.touch[s] = 0;
@@ -1969,7 +1995,7 @@ dmc_init_episode(DmcArgs a) {
     for (int i = 0; i < NV; i++) qvel[i] = R(0.01)*rng.normal();
   } else if (TASK == TASK_CHEETAH || TASK == TASK_HUMANOID ||
              TASK == TASK_WALKER || TASK == TASK_PENDULUM || TASK == TASK_ACROBOT ||
-             TASK == TASK_HOPPER) {
+             TASK == TASK_HOPPER || TASK == TASK_REACHER) {
     DMC_UNROLL
     for (int j = 0; j < NJNT; j++) {
       const int qa = jnt_qposadr[j];
@@ -1990,6 +2016,13 @@ dmc_init_episode(DmcArgs a) {
       }
     }
   }
+  if (TASK == TASK_REACHER && !(a.flags & DMC_FLAG_RESET_ONLY)) {
+    // reacher.py:100-104: target on a ring around the shoulder
+    const real angle = R(6.283185307179586)*rng.uniform();
+    const real radius = R(0.05) + R(0.15)*rng.uniform();
+    a.taskdata[sidx(0, e, n, NTDX)] = radius*sin(angle);
+    a.taskdata[sidx(1, e, n, NTDX)] = radius*cos(angle);
+  }
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) a.qpos[sidx(i, e, n, NQX)] = qpos[i];
   DMC_UNROLL
@@ -2002,9 +2035,9 @@ dmc_init_episode(DmcArgs a) {
 
 #ifndef DMC_COOP_BUILD
 // self-description read by dmc_api.cpp through hipModuleGetGlobal
-extern "C" __device__ const int dmc_info[16] = {
+extern "C" __device__ const int dmc_info[20] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     (WS_WORDS > 0 ? WS_WORDS : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
     INTEGRATOR, NPAIR, 64 /*envs per 64-lane workgroup of dmc_step/dmc_observe*/,
-    DMC_ENV_MAJOR /*0: state fields are [k][env]*/};
+    DMC_ENV_MAJOR /*0: state fields are [k][env]*/, NTASKDATA, 0, 0, 0};
 #endif

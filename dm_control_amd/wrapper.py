@@ -23,7 +23,7 @@ _DEFAULT_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)),
 # enum dmc_field
 (FIELD_QPOS, FIELD_QVEL, FIELD_WARMSTART, FIELD_TIME, FIELD_CTRL, FIELD_OBS,
  FIELD_REWARD, FIELD_SENSORDATA, FIELD_XPOS, FIELD_XMAT, FIELD_QACC,
- FIELD_WARN, FIELD_STATS, FIELD_RETURN) = range(14)
+ FIELD_WARN, FIELD_STATS, FIELD_RETURN, FIELD_TASKDATA) = range(15)
 
 
 class Error(Exception):
@@ -34,7 +34,7 @@ class ModelInfo(ctypes.Structure):
   _fields_ = [(n, ctypes.c_int) for n in (
       'abi', 'real_size', 'nq', 'nv', 'nu', 'nbody', 'nobs', 'nsensordata',
       'ws_per_env', 'task', 'ncon_max', 'nefc_max', 'integrator', 'npair',
-      'lanes_per_env', 'env_major')]
+      'ntaskdata', 'lanes_per_env', 'env_major')]
 
 
 # every symbol declared in include/dmc_hip.h: (restype, argtypes)
@@ -55,6 +55,7 @@ SIGNATURES = {
         _ci, [_vp, _ci, ctypes.POINTER(ctypes.c_double), _ci]),
     'dmc_batch_reset': (_ci, [_vp]),
     'dmc_batch_set_state': (_ci, [_vp, _vp, _vp, _vp, _vp]),
+    'dmc_batch_write': (_ci, [_vp, _ci, _vp, _cs]),
     'dmc_batch_init_episode': (_ci, [_vp, ctypes.c_uint64, _ci]),
     'dmc_batch_forward': (_ci, [_vp, _ci]),
     'dmc_batch_step': (_ci, [_vp, _vp, _cll, _cll, _ci, _ci, _ci]),
@@ -159,7 +160,7 @@ class HipBatch:
         FIELD_REWARD: (n,), FIELD_SENSORDATA: (max(i.nsensordata, 1), n),
         FIELD_XPOS: (i.nbody*3, n), FIELD_XMAT: (i.nbody*9, n),
         FIELD_QACC: (max(i.nv, 1), n), FIELD_WARN: (n,), FIELD_STATS: (3, n),
-        FIELD_RETURN: (n,),
+        FIELD_RETURN: (n,), FIELD_TASKDATA: (max(i.ntaskdata, 1), n),
     }[field]
 
   def _dtype(self, field):
@@ -182,6 +183,14 @@ class HipBatch:
   # -- state ------------------------------------------------------------------
   def reset(self):
     _check(self._lib.dmc_batch_reset(self.ptr))
+
+  def write(self, field, array):
+    """Uploads a writable field given as [k][nenv] (any float dtype)."""
+    a = np.ascontiguousarray(array, dtype=self.model.dtype)
+    if a.shape != self._shape(field):
+      raise ValueError('expected shape {}, got {}'.format(
+          self._shape(field), a.shape))
+    _check(self._lib.dmc_batch_write(self.ptr, field, a.ctypes.data, a.nbytes))
 
   def set_state(self, qpos=None, qvel=None, warmstart=None, time=None):
     """Uploads [k][nenv] arrays (any float dtype; converted to the batch's)."""

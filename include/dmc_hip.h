@@ -61,7 +61,10 @@ enum dmc_field {
   DMC_FIELD_WARN = 11,      /* uint32 [nenv] sticky mjtWarning bit mask */
   DMC_FIELD_STATS = 12,     /* int32 [3][nenv]: ncon, nefc, solver iterations */
   DMC_FIELD_RETURN = 13,    /* real [nenv] sum of rewards since the last reset */
-  DMC_FIELD_COUNT = 14
+  DMC_FIELD_TASKDATA = 14,  /* real [ntaskdata][nenv] per-instance task parameters (e.g.
+                               the reacher's target position, which the reference
+                               writes into model.geom_pos per episode) */
+  DMC_FIELD_COUNT = 15
 };
 
 enum dmc_warn_bit {
@@ -74,6 +77,7 @@ enum dmc_warn_bit {
 typedef struct dmc_model_info {
   int abi, real_size, nq, nv, nu, nbody, nobs, nsensordata, ws_per_env, task,
       ncon_max, nefc_max, integrator, npair,
+      ntaskdata,     /* per-instance task parameters (DMC_FIELD_TASKDATA rows) */
       lanes_per_env, /* 1, or the group size of a several-lanes-per-env build */
       env_major;     /* 1: the 2-D state fields are [nenv][k] in HBM (what
                         dmc_batch_device_ptr returns); dmc_batch_read and
@@ -110,6 +114,10 @@ int dmc_batch_reset(dmc_batch* batch);
 /* explicit state upload, host pointers, `real`-typed [k][nenv]; NULL = keep */
 int dmc_batch_set_state(dmc_batch* batch, const void* qpos, const void* qvel,
                         const void* warmstart, const void* time);
+/* generic host -> device write of a writable field (QPOS, QVEL, WARMSTART,
+ * TIME, TASKDATA), `real`-typed [k][nenv]; replaces the reference's in-place
+ * writes through numpy views on mjData / mjModel (wrapper/core.py:630-776) */
+int dmc_batch_write(dmc_batch* batch, int field, const void* src, size_t bytes);
 /* task.initialize_episode on device (counter-based RNG keyed by seed, env).
  * only_colliding != 0 redraws only envs whose last contact count was > 0. */
 int dmc_batch_init_episode(dmc_batch* batch, uint64_t seed, int only_colliding);

@@ -121,10 +121,10 @@ def rewards_golden():
 
 def tasks_golden():
   from dm_control.suite import (acrobot, cartpole, cheetah, hopper, humanoid,
-                                pendulum, walker)
+                                pendulum, reacher, walker)
   rs = np.random.RandomState(1)
   out = {'cartpole': [], 'cheetah': [], 'humanoid': [], 'walker': [],
-         'pendulum': [], 'acrobot': [], 'hopper': []}
+         'pendulum': [], 'acrobot': [], 'hopper': [], 'reacher': []}
 
   for _ in range(24):
     x, cos, ctrl = rs.uniform(-2, 2), rs.uniform(-1, 1), rs.uniform(-1.5, 1.5)
@@ -233,6 +233,24 @@ def tasks_golden():
       t = hopper.Hopper(hopping=hopping, random=0)
       rec['reward_hop' if hopping else 'reward_stand'] = float(t.get_reward(P()))
     out['hopper'].append(rec)
+
+  class _Sizes:   # named.model.geom_size[['target', 'finger'], 0]
+    def __init__(self, target): self._v = {'target': target, 'finger': 0.01}
+    def __getitem__(self, key):
+      names, col = key
+      assert col == 0
+      return np.array([self._v[n] for n in names])
+  for _ in range(24):
+    vec = rs.uniform(-0.08, 0.08, 2) if rs.rand() < 0.6 else rs.uniform(-0.3, 0.3, 2)
+    rec = dict(to_target=vec.tolist(), dist=float(np.linalg.norm(vec)))
+    for size in (0.05, 0.015):
+      class P(reacher.Physics):
+        named = types.SimpleNamespace(model=types.SimpleNamespace(
+            geom_size=_Sizes(size)))
+        def finger_to_target(self): return vec
+      rec['reward_%g' % size] = float(
+          reacher.Reacher(target_size=size, random=0).get_reward(P()))
+    out['reacher'].append(rec)
   return out
 
 

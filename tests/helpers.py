@@ -10,11 +10,11 @@ from dm_control_amd.mjcf import compiler
 TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
          'humanoid': codegen.TASK_HUMANOID, 'walker': codegen.TASK_WALKER,
          'pendulum': codegen.TASK_PENDULUM, 'acrobot': codegen.TASK_ACROBOT,
-         'hopper': codegen.TASK_HOPPER}
+         'hopper': codegen.TASK_HOPPER, 'reacher': codegen.TASK_REACHER}
 # build mode per suite model (humanoid: see suite/humanoid.py)
 MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'coop',
          'walker': 'auto', 'pendulum': 'auto', 'acrobot': 'auto',
-         'hopper': 'auto'}
+         'hopper': 'auto', 'reacher': 'auto'}
 
 
 def model_xml(name):
@@ -52,6 +52,10 @@ def initial_states(model, name, nenv, seed):
     qpos[:, 1] = rs.uniform(-0.16, -0.04, nenv)   # rootz: foot near / into the floor
     qpos[:, 2] = rs.uniform(-0.2, 0.2, nenv)
     qvel[:] = 0.5*rs.randn(nenv, model.nv)
+  elif name == 'reacher':
+    qpos[:, 0] = rs.uniform(-np.pi, np.pi, nenv)
+    qpos[:, 1] = rs.uniform(-2.7, 2.7, nenv)
+    qvel[:] = 3*rs.randn(nenv, 2)
   elif name == 'acrobot':
     qpos[:] = rs.uniform(-np.pi, np.pi, (nenv, 2))
     qvel[:] = 2*rs.randn(nenv, 2)

@@ -89,3 +89,8 @@ def hopper_reward(height, speed, ctrl, hopping):
   small_control = rewards.tolerance(np.asarray(ctrl), margin=1, value_at_margin=0,
                                     sigmoid='quadratic').mean()
   return standing*(small_control + 4)/5
+
+
+def reacher_reward(finger_to_target_dist, target_size, finger_size=0.01):
+  """suite/reacher.py:118-120."""
+  return rewards.tolerance(finger_to_target_dist, (0, target_size + finger_size))

@@ -17,7 +17,7 @@ REF_SUITE = '/root/reference/dm_control/suite'
 
 
 @pytest.mark.parametrize('name', ['cartpole', 'cheetah', 'humanoid', 'walker',
-                                  'pendulum', 'acrobot', 'hopper'])
+                                  'pendulum', 'acrobot', 'hopper', 'reacher'])
 def test_in_tree_models_compile_like_the_reference_files(name):
   """The in-tree parameter tables (suite/models/*.py) give the same compiled
   model, names and ordering included, as the reference's MJCF files (which also

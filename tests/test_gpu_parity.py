@@ -99,7 +99,7 @@ def _teacher_forced(name, precision, nenv, steps, nsub, lds_budget=None,
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
                                        ('humanoid', 5), ('walker', 10),
                                        ('pendulum', 1), ('acrobot', 1),
-                                       ('hopper', 4)])
+                                       ('hopper', 4), ('reacher', 1)])
 def test_fp64_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f64', nenv=64, steps=12, nsub=nsub)
   assert e.max() <= 1e-9, e.max()
@@ -108,7 +108,7 @@ def test_fp64_build_matches_oracle_per_step(name, nsub):
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
                                        ('humanoid', 5), ('walker', 10),
                                        ('pendulum', 1), ('acrobot', 1),
-                                       ('hopper', 4)])
+                                       ('hopper', 4), ('reacher', 1)])
 def test_fp32_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f32', nenv=128, steps=12, nsub=nsub)
   assert np.median(e) <= 2e-6, np.median(e)
@@ -336,7 +336,8 @@ def test_fused_task_outputs_match_reference_formulas():
                              ('pendulum', 'swingup', 64),
                              ('acrobot', 'swingup', 64),
                              ('acrobot', 'swingup_sparse', 64),
-                             ('hopper', 'stand', 32), ('hopper', 'hop', 32)):
+                             ('hopper', 'stand', 32), ('hopper', 'hop', 32),
+                             ('reacher', 'easy', 64), ('reacher', 'hard', 64)):
     env = suite.load(domain, task, task_kwargs={'random': 4},
                      environment_kwargs={'batch_size': nenv})
     physics = env.physics
@@ -373,6 +374,19 @@ def test_fused_task_outputs_match_reference_formulas():
                                    xmat[i, 1:][:, [0, 2]].ravel(), atol=1e-6)
         np.testing.assert_allclose(ts.observation['height'][i],
                                    xpos[i, torso, 2])
+      elif domain == 'reacher':
+        m = physics.model
+        finger = xpos[i, m.name2id('finger', 'body'), :2]
+        target = physics.target_position()[i]
+        assert 0.05 - 1e-6 <= np.linalg.norm(target) <= 0.2 + 1e-6
+        want = task_formulas.reacher_reward(
+            np.linalg.norm(target - finger), {'easy': .05, 'hard': .015}[task])
+        np.testing.assert_allclose(ts.observation['to_target'][i], target - finger,
+                                   atol=1e-6)
+        np.testing.assert_allclose(physics.finger_to_target_dist()[i],
+                                   np.linalg.norm(target - finger), atol=1e-6)
+        if abs(np.linalg.norm(target - finger) - ({'easy': .05, 'hard': .015}[task] + .01)) < 1e-5:
+          continue     # on the rim of the indicator reward
       elif domain == 'hopper':
         sens = np.asarray(physics.data.sensordata)[i]
         want = task_formulas.hopper_reward(physics.height()[i], sens[0], ctrl[i],
@@ -551,6 +565,37 @@ def test_checkpoint_round_trip_continues_bit_for_bit(tmp_path):
     small.physics.load_checkpoint(path)
   for e in (env, other, small):
     e.physics.free()
+
+
+def test_per_instance_task_data_write_and_device_init():
+  """DMC_FIELD_TASKDATA (the reacher's target, which the reference rewrites in
+  model.geom_pos): host writes round-trip through dmc_batch_write / read in the
+  [k][nenv] presentation, and the device-side initialiser draws the same ring
+  distribution (reacher.py:100-104)."""
+  env = suite.load('reacher', 'easy', task_kwargs={'random': 5},
+                   environment_kwargs={'batch_size': 256})
+  env.reset()
+  batch = env.physics.batch
+  t = np.random.RandomState(0).uniform(-0.2, 0.2, (2, 256))
+  batch.write(W.FIELD_TASKDATA, t)
+  np.testing.assert_allclose(batch.read(W.FIELD_TASKDATA), t, atol=1e-7)
+  with pytest.raises(W.Error):
+    batch.write(W.FIELD_OBS, np.zeros((256, 6)))      # not writable
+  with pytest.raises(ValueError):
+    batch.write(W.FIELD_TASKDATA, np.zeros((3, 256)))
+  ts = env.step(np.zeros((256, 2)))
+  finger = np.asarray(env.physics.data.xpos).reshape(256, -1, 3)[:, 3, :2]
+  np.testing.assert_allclose(ts.observation['to_target'], t.T - finger, atol=1e-6)
+  env.physics.free()
+  dev = suite.load('reacher', 'hard', task_kwargs={'random': 5},
+                   environment_kwargs={'batch_size': 4096, 'device_init': True})
+  dev.reset()
+  r = np.linalg.norm(dev.physics.target_position(), axis=1)
+  assert r.min() >= 0.05 - 1e-6 and r.max() <= 0.2 + 1e-6
+  assert abs(r.mean() - 0.125) < 0.01 and r.std() > 0.03
+  ang = np.arctan2(*dev.physics.target_position().T)
+  assert abs(ang.mean()) < 0.15 and ang.std() > 1.5
+  dev.physics.free()
 
 
 def test_c_abi_argument_errors():
