@@ -21,7 +21,7 @@ from dm_control_amd.mjcf import model as mdl
 
 TASK_NONE, TASK_CARTPOLE, TASK_CHEETAH, TASK_HUMANOID = 0, 1, 2, 3
 TASK_WALKER, TASK_PENDULUM, TASK_ACROBOT, TASK_HOPPER = 4, 5, 6, 7
-TASK_REACHER = 8
+TASK_REACHER, TASK_POINTMASS = 8, 9
 SENS_TOUCH = 0
 
 _SUPPORTED_PAIRS = {
@@ -142,6 +142,8 @@ def task_bodies(m, task):
     return [m.name2id('torso', 'body'), m.name2id('foot', 'body')]
   if task == TASK_REACHER:
     return [m.name2id('finger', 'body')]
+  if task == TASK_POINTMASS:
+    return [m.name2id('pointmass', 'body')]
   if task == TASK_HUMANOID:
     return [m.name2id(n, 'body') for n in
             ('torso', 'head', 'left_hand', 'left_foot', 'right_hand',
@@ -166,18 +168,29 @@ def observation_size(m, task):
     return (m.nq - 1) + m.nv + 2
   if task == TASK_REACHER:
     return m.nq + 2 + m.nv
+  if task == TASK_POINTMASS:
+    return m.nq + m.nv
   return m.nq + m.nv
 
 
 def task_data_size(task):
   """Per-instance task parameters (DMC_FIELD_TASKDATA rows)."""
-  return {TASK_REACHER: 2}.get(task, 0)     # reacher: target x, y
+  # reacher: target x, y; point_mass: the 4 tendon coefficients (wrap_prm)
+  return {TASK_REACHER: 2, TASK_POINTMASS: 4}.get(task, 0)
+
+
+def task_data_default(m, task):
+  """Values the per-instance task data starts with (the compiled model's)."""
+  if task == TASK_POINTMASS:
+    return [float(v) for v in m.wrap_prm[:4]]
+  return [0.0]*task_data_size(task)
 
 
 def task_sites(m, task):
   """Sites a task's reward reads: [(body id, local pos[3], size[0])]."""
   names = {TASK_ACROBOT: ('tip', 'target'),
-           TASK_REACHER: ('geom:finger', 'geom:target')}.get(task, ())
+           TASK_REACHER: ('geom:finger', 'geom:target'),
+           TASK_POINTMASS: ('geom:pointmass', 'geom:target')}.get(task, ())
   out = []
   for n in names:
     if n.startswith('geom:'):     # a geom frame used like a site
@@ -299,6 +312,7 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   ci('NLIMIT', len(limit_jnt)); ci('TASK', task)
   ci('NOBS', observation_size(m, task))
   ci('NTASKDATA', task_data_size(task))
+  tr('task_data_default', task_data_default(m, task) or [0])
   cd('timestep', dt); cd('tolerance_opt', m.opt.tolerance)
   cd('meaninertia', m.meaninertia)
   tr('gravity', m.opt.gravity)
@@ -319,6 +333,27 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
                'actuator_ctrlrange', 'actuator_forcerange',
                'actuator_gainprm', 'actuator_biasprm'):
     tr(name, getattr(m, name))
+  # actuator transmissions flattened to (dof, qpos address, coefficient) lists:
+  # one entry for a joint, one per wrapped joint for a fixed tendon
+  w_adr, w_num, w_dof, w_qadr, w_coef = [], [], [], [], []
+  for u in range(m.nu):
+    w_adr.append(len(w_dof))
+    if int(m.actuator_trntype[u]) == mdl.TRN_TENDON:
+      t = int(m.actuator_trnid[u])
+      items = [(int(m.wrap_objid[k]), float(m.wrap_prm[k]))
+               for k in range(int(m.tendon_adr[t]),
+                              int(m.tendon_adr[t] + m.tendon_num[t]))]
+    else:
+      items = [(int(m.actuator_trnid[u]), 1.0)]
+    for j, coef in items:
+      w_dof.append(int(m.jnt_dofadr[j]))
+      w_qadr.append(int(m.jnt_qposadr[j]))
+      w_coef.append(coef)
+    w_num.append(len(w_dof) - w_adr[-1])
+  ci('MAXWRAP', max(w_num + [1]))
+  ti('act_wrap_adr', w_adr); ti('act_wrap_num', w_num)
+  ti('act_wrap_dof', w_dof); ti('act_wrap_qadr', w_qadr)
+  tr('act_wrap_coef', w_coef)
   ti('limit_jnt', limit_jnt)
   tr('limit_K', limit_k); tr('limit_B', limit_b)
   tr('limit_solimp', limit_solimp)

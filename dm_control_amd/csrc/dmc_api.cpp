@@ -263,6 +263,12 @@ int dmc_batch_create(const dmc_model* model, int nenv, dmc_batch** out) {
     return fail("dmc_batch_create: %s", hipGetErrorString(err));
   }
   *out = b;
+  {   // per-instance task data starts from the compiled model's values
+    DmcArgs a;
+    fill_args(b, a);
+    a.flags = DMC_FLAG_RESET_ONLY | DMC_FLAG_TASKDATA_DEFAULT;
+    if (launch(b, model->k_init, a)) return -1;
+  }
   return dmc_batch_reset(b);
 }
 

@@ -715,21 +715,37 @@ struct Coop {
         fs -= R(dof_damping[i])*S[off::QVEL + i];
       }
       if (actuation && !(DISABLEFLAGS & DSBL_ACTUATION)) {
+        const EnvView V = {S + off::QPOS, S + off::QVEL, S + off::CTRL, S + off::XPOS,
+                           S + off::XMAT, S + off::XIPOS, S + off::SLV, S + off::TOUCH,
+                           S + off::TASKD};
         for (int u = 0; u < NU; u++) {
-          const int j = actuator_trnid[u], dof = jnt_dofadr[j];
-          if (dof != i) continue;
+          // does this actuator's transmission reach dof i?
+          real moment = 0;
+          bool mine = false;
+          for (int k = 0; k < act_wrap_num[u]; k++) {
+            const int w = act_wrap_adr[u] + k;
+            if (act_wrap_dof[w] == i) { moment += wrap_coef(V, w); mine = true; }
+          }
+          if (!mine) continue;
           const real gear = R(actuator_gear[u]);
           real c = S[off::CTRL + u];
           if (actuator_ctrllimited[u] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
             c = clampr(c, R(actuator_ctrlrange[2*u]), R(actuator_ctrlrange[2*u + 1]));
           real force = R(actuator_gainprm[3*u])*c;
-          if (actuator_biastype[u] == 1)
-            force += R(actuator_biasprm[3*u]) +
-                     R(actuator_biasprm[3*u + 1])*gear*S[off::QPOS + jnt_qposadr[j]] +
-                     R(actuator_biasprm[3*u + 2])*gear*S[off::QVEL + dof];
+          if (actuator_biastype[u] == 1) {
+            real length = 0, velocity = 0;
+            for (int k = 0; k < act_wrap_num[u]; k++) {
+              const int w = act_wrap_adr[u] + k;
+              const real coef = wrap_coef(V, w);
+              length += coef*S[off::QPOS + act_wrap_qadr[w]];
+              velocity += coef*S[off::QVEL + act_wrap_dof[w]];
+            }
+            force += R(actuator_biasprm[3*u]) + R(actuator_biasprm[3*u + 1])*gear*length +
+                     R(actuator_biasprm[3*u + 2])*gear*velocity;
+          }
           if (actuator_forcelimited[u])
             force = clampr(force, R(actuator_forcerange[2*u]), R(actuator_forcerange[2*u + 1]));
-          fs += gear*force;
+          fs += gear*moment*force;
         }
       }
       S[off::FS + i] = fs;

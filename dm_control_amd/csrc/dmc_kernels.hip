@@ -85,7 +85,7 @@ enum { WARN_INERTIA = 1, WARN_CONTACTFULL = 2, WARN_CNSTRFULL = 4,
        WARN_BADCTRL = 128 };
 enum { TASK_NONE = 0, TASK_CARTPOLE = 1, TASK_CHEETAH = 2, TASK_HUMANOID = 3,
        TASK_WALKER = 4, TASK_PENDULUM = 5, TASK_ACROBOT = 6, TASK_HOPPER = 7,
-       TASK_REACHER = 8 };
+       TASK_REACHER = 8, TASK_POINTMASS = 9 };
 
 #define DMC_REALPTR real*
 #define DMC_CREALPTR const real*
@@ -662,6 +662,13 @@ DEV void com_vel(Env& E) {
   }
 }
 
+// coefficient of transmission entry w (compile-time, or per-instance task data)
+template <class EnvT>
+DEV real wrap_coef(const EnvT& E, int w) {
+  if (TASK == TASK_POINTMASS) return E.taskdata[w];
+  return R(act_wrap_coef[w]);
+}
+
 // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
 DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
   real cacc[NBODY*6], cfrc[NBODY*6];
@@ -709,21 +716,34 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
       E.qfrc_smooth[i] -= R(dof_damping[i])*E.qvel[i];
   }
   if (actuation && !(DISABLEFLAGS & DSBL_ACTUATION)) {
+    // transmission = list of (dof, coefficient): a joint, or the joints a fixed
+    // tendon wraps; the point-mass task varies the coefficients per instance
     DMC_UNROLL
     for (int i = 0; i < NU; i++) {
-      const int j = actuator_trnid[i], dof = jnt_dofadr[j];
       const real gear = R(actuator_gear[i]);
       real c = E.ctrl[i];
       if (actuator_ctrllimited[i] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
         c = clampr(c, R(actuator_ctrlrange[2*i]), R(actuator_ctrlrange[2*i + 1]));
       real force = R(actuator_gainprm[3*i])*c;
-      if (actuator_biastype[i] == 1)
-        force += R(actuator_biasprm[3*i]) +
-                 R(actuator_biasprm[3*i + 1])*gear*E.qpos[jnt_qposadr[j]] +
-                 R(actuator_biasprm[3*i + 2])*gear*E.qvel[dof];
+      if (actuator_biastype[i] == 1) {
+        real length = 0, velocity = 0;
+        DMC_UNROLL
+        for (int k = 0; k < act_wrap_num[i]; k++) {
+          const int w = act_wrap_adr[i] + k;
+          const real coef = wrap_coef(E, w);
+          length += coef*E.qpos[act_wrap_qadr[w]];
+          velocity += coef*E.qvel[act_wrap_dof[w]];
+        }
+        force += R(actuator_biasprm[3*i]) + R(actuator_biasprm[3*i + 1])*gear*length +
+                 R(actuator_biasprm[3*i + 2])*gear*velocity;
+      }
       if (actuator_forcelimited[i])
         force = clampr(force, R(actuator_forcerange[2*i]), R(actuator_forcerange[2*i + 1]));
-      E.qfrc_smooth[dof] += gear*force;
+      DMC_UNROLL
+      for (int k = 0; k < act_wrap_num[i]; k++) {
+        const int w = act_wrap_adr[i] + k;
+        E.qfrc_smooth[act_wrap_dof[w]] += gear*wrap_coef(E, w)*force;
+      }
     }
   }
   DMC_UNROLL
@@ -1726,6 +1746,32 @@ DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
       for (int i = 0; i < NU; i++) sc += tolerance(E.ctrl[i], 0, 0, 1, SIG_QUADRATIC, 0);
       reward = standing*(sc/NU + 4)/5;
     }
+  } else if (TASK == TASK_POINTMASS) {
+    // point_mass.py:59-130; task_site = pointmass geom, target geom
+    int o = 0;
+    DMC_UNROLL
+    for (int i = 0; i < NQ; i++) OBS(o++) = E.qpos[i];
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) OBS(o++) = E.qvel[i];
+    real d2 = 0;
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      real p[2];
+      DMC_UNROLL
+      for (int s = 0; s < 2; s++) {
+        const int b = task_site_body[s];
+        p[s] = E.xpos[3*b + k] + E.xmat[9*b + 3*k]*R(task_site_pos[3*s]) +
+               E.xmat[9*b + 3*k + 1]*R(task_site_pos[3*s + 1]) +
+               E.xmat[9*b + 3*k + 2]*R(task_site_pos[3*s + 2]);
+      }
+      d2 += (p[1] - p[0])*(p[1] - p[0]);
+    }
+    const real size = R(task_site_size[1]);
+    const real near = tolerance(sqrt(d2), 0, size, size, SIG_GAUSSIAN, R(0.1));
+    real sc = 0;
+    DMC_UNROLL
+    for (int i = 0; i < NU; i++) sc += tolerance(E.ctrl[i], 0, 0, 1, SIG_QUADRATIC, 0);
+    reward = near*(sc/NU + 4)/5;
   } else if (TASK == TASK_REACHER) {
     // reacher.py:64-122; task_body = finger; task_site = finger geom, target
     // geom; the target's x, y are per-instance data (the reference rewrites
@@ -1995,7 +2041,7 @@ dmc_init_episode(DmcArgs a) {
     for (int i = 0; i < NV; i++) qvel[i] = R(0.01)*rng.normal();
   } else if (TASK == TASK_CHEETAH || TASK == TASK_HUMANOID ||
              TASK == TASK_WALKER || TASK == TASK_PENDULUM || TASK == TASK_ACROBOT ||
-             TASK == TASK_HOPPER || TASK == TASK_REACHER) {
+             TASK == TASK_HOPPER || TASK == TASK_REACHER || TASK == TASK_POINTMASS) {
     DMC_UNROLL
     for (int j = 0; j < NJNT; j++) {
       const int qa = jnt_qposadr[j];
@@ -2015,6 +2061,29 @@ dmc_init_episode(DmcArgs a) {
         }
       }
     }
+  }
+  if (a.flags & DMC_FLAG_TASKDATA_DEFAULT) {   // batch creation: the compiled model's values
+    DMC_UNROLL
+    for (int i = 0; i < NTASKDATA; i++)
+      a.taskdata[sidx(i, e, n, NTDX)] = R(task_data_default[i]);
+  }
+  if (TASK == TASK_POINTMASS && !(a.flags & DMC_FLAG_RESET_ONLY)) {
+    // point_mass.py:103-113: each control drives a random direction in the
+    // plane ("hard"), or the model's own axes ("easy")
+    real d1[2] = {R(task_data_default[0]), R(task_data_default[1])};
+    real d2[2] = {R(task_data_default[2]), R(task_data_default[3])};
+    if (a.task_param_i & 1) {
+      real nrm;
+      d1[0] = rng.normal(); d1[1] = rng.normal();
+      nrm = sqrt(d1[0]*d1[0] + d1[1]*d1[1]); d1[0] /= nrm; d1[1] /= nrm;
+      for (int tries = 0; tries < 64; tries++) {
+        d2[0] = rng.normal(); d2[1] = rng.normal();
+        nrm = sqrt(d2[0]*d2[0] + d2[1]*d2[1]); d2[0] /= nrm; d2[1] /= nrm;
+        if (!(fabs(d1[0]*d2[0] + d1[1]*d2[1]) > R(0.9))) break;
+      }
+    }
+    a.taskdata[sidx(0, e, n, NTDX)] = d1[0]; a.taskdata[sidx(1, e, n, NTDX)] = d1[1];
+    a.taskdata[sidx(2, e, n, NTDX)] = d2[0]; a.taskdata[sidx(3, e, n, NTDX)] = d2[1];
   }
   if (TASK == TASK_REACHER && !(a.flags & DMC_FLAG_RESET_ONLY)) {
     // reacher.py:100-104: target on a ring around the shoulder

@@ -37,7 +37,7 @@ class CompileError(ValueError):
 
 
 _ACTUATOR_TAGS = ('motor', 'position', 'velocity', 'general')
-_UNSUPPORTED_SECTIONS = ('tendon', 'equality', 'keyframe', 'custom')
+_UNSUPPORTED_SECTIONS = ('equality', 'keyframe', 'custom')
 _IGNORED_SECTIONS = ('asset', 'visual', 'statistic', 'size')
 _IGNORED_BODY_CHILDREN = ('light', 'camera')
 
@@ -552,7 +552,7 @@ class _Compiler:
           raise CompileError('<%s> is not supported' % sec)
     known = set(_UNSUPPORTED_SECTIONS + _IGNORED_SECTIONS + (
         'compiler', 'option', 'default', 'worldbody', 'actuator', 'sensor',
-        'contact'))
+        'contact', 'tendon'))
     for e in root:
       if e.tag not in known:
         raise CompileError('unknown top-level element <%s>' % e.tag)
@@ -572,6 +572,7 @@ class _Compiler:
     self._add_body(world, -1, None)
 
     self._finish_tree(m)
+    self._finish_tendons(m)
     self._finish_actuators(m)
     self._finish_sensors(m)
     self._finish_contact(m)
@@ -791,6 +792,37 @@ class _Compiler:
     m.site_type = np.array([s['type'] for s in self.sites], np.int32)
     self.joints, self.geoms = joints, geoms
 
+  def _finish_tendons(self, m):
+    """Fixed tendons: length = sum_j coef_j * q_j (used as actuator
+    transmissions).  Spatial tendons and tendon springs, dampers and limits are
+    not implemented."""
+    names, adr, num, objid, prm = [], [], [], [], []
+    for sec in self.root.findall('tendon'):
+      for t in sec:
+        if t.tag != 'fixed':
+          raise CompileError('tendon <%s> is not supported' % t.tag)
+        a = self.defaults.resolve(t, None)
+        for attr in ('limited', 'stiffness', 'damping', 'frictionloss', 'margin'):
+          if attr in a and a[attr] not in ('false', '0', '0.0'):
+            raise CompileError('tendon attribute %r is not supported' % attr)
+        names.append(a.get('name'))
+        adr.append(len(objid))
+        for w in t:
+          if w.tag != 'joint':
+            raise CompileError('fixed tendons wrap joints only')
+          jid = m.name2id(w.get('joint'), 'joint')
+          if m.jnt_type[jid] not in (mdl.JNT_HINGE, mdl.JNT_SLIDE):
+            raise CompileError('tendons over free/ball joints not supported')
+          objid.append(jid)
+          prm.append(float(w.get('coef')))
+        num.append(len(objid) - adr[-1])
+    m.ntendon, m.nwrap = len(names), len(objid)
+    m.tendon_adr = np.array(adr, np.int32)
+    m.tendon_num = np.array(num, np.int32)
+    m.wrap_objid = np.array(objid, np.int32)
+    m.wrap_prm = np.array(prm, np.float64)
+    m.names['tendon'] = names
+
   def _finish_actuators(self, m):
     acts = []
     for sec in self.root.findall('actuator'):
@@ -798,11 +830,14 @@ class _Compiler:
         if e.tag not in _ACTUATOR_TAGS:
           raise CompileError('actuator <%s> is not supported' % e.tag)
         a = self.defaults.resolve(e, None)
-        if 'joint' not in a:
-          raise CompileError('only joint transmissions are supported')
-        jid = m.name2id(a['joint'], 'joint')
-        if m.jnt_type[jid] not in (mdl.JNT_HINGE, mdl.JNT_SLIDE):
-          raise CompileError('actuators on free/ball joints not supported')
+        if 'tendon' in a:
+          trntype, jid = mdl.TRN_TENDON, m.name2id(a['tendon'], 'tendon')
+        elif 'joint' in a:
+          trntype, jid = mdl.TRN_JOINT, m.name2id(a['joint'], 'joint')
+          if m.jnt_type[jid] not in (mdl.JNT_HINGE, mdl.JNT_SLIDE):
+            raise CompileError('actuators on free/ball joints not supported')
+        else:
+          raise CompileError('only joint and tendon transmissions are supported')
         gear = _floats(a.get('gear', '1'))[0]
         gain = [1.0, 0.0, 0.0]
         bias = [0.0, 0.0, 0.0]
@@ -828,7 +863,8 @@ class _Compiler:
           elif bt != 'none':
             raise CompileError('biastype %r not supported' % bt)
         acts.append(dict(
-            name=a.get('name'), trnid=jid, gear=gear, gain=gain, bias=bias,
+            name=a.get('name'), trnid=jid, trntype=trntype, gear=gear, gain=gain,
+            bias=bias,
             gaintype=gaintype, biastype=biastype,
             ctrllimited=_bool(a.get('ctrllimited', 'false'), 'ctrllimited'),
             ctrlrange=_floats(a.get('ctrlrange', '0 0'), 2, 'ctrlrange'),
@@ -837,7 +873,7 @@ class _Compiler:
             forcerange=_floats(a.get('forcerange', '0 0'), 2, 'forcerange')))
     nu = len(acts)
     m.nu = nu
-    m.actuator_trntype = np.full(nu, mdl.TRN_JOINT, np.int32)
+    m.actuator_trntype = np.array([a['trntype'] for a in acts], np.int32)
     m.actuator_trnid = np.array([a['trnid'] for a in acts], np.int32)
     m.actuator_ctrllimited = np.array([int(a['ctrllimited']) for a in acts],
                                       np.int32)

@@ -23,6 +23,7 @@ SOLVER_PGS, SOLVER_CG, SOLVER_NEWTON = 0, 1, 2
 GAIN_FIXED = 0
 BIAS_NONE, BIAS_AFFINE = 0, 1
 TRN_JOINT = 0
+TRN_TENDON = 3          # mjTRN_TENDON
 
 # mjtDisableBit
 DSBL_CONSTRAINT = 1 << 0
@@ -85,6 +86,7 @@ WARNING_NAMES = ('mjWARN_INERTIA', 'mjWARN_CONTACTFULL', 'mjWARN_CNSTRFULL',
 FIELDS = (
     ('nq', 'i'), ('nv', 'i'), ('nu', 'i'), ('nbody', 'i'), ('njnt', 'i'),
     ('ngeom', 'i'), ('nsensor', 'i'), ('nsensordata', 'i'), ('nexclude', 'i'),
+    ('ntendon', 'i'), ('nwrap', 'i'),
     ('integrator', 'i'), ('cone', 'i'), ('solver', 'i'), ('iterations', 'i'),
     ('disableflags', 'i'), ('enableflags', 'i'),
     ('timestep', 'd'), ('tolerance', 'd'), ('impratio', 'd'),
@@ -115,6 +117,8 @@ FIELDS = (
     ('actuator_gear', 'D'), ('actuator_ctrlrange', 'D'),
     ('actuator_forcerange', 'D'), ('actuator_gainprm', 'D'),
     ('actuator_biasprm', 'D'),
+    ('tendon_adr', 'I'), ('tendon_num', 'I'), ('wrap_objid', 'I'),
+    ('wrap_prm', 'D'),
     ('sensor_type', 'I'), ('sensor_objid', 'I'), ('sensor_adr', 'I'),
     ('sensor_dim', 'I'),
     ('exclude_signature', 'I'),

@@ -5,7 +5,7 @@ Same contract as /root/reference/dm_control/suite/__init__.py:78-150:
 visualize_reward)` returns a `control.Environment`; unknown names raise
 ValueError; the tag-derived constants exist.  Domains currently built on the
 HIP path: cartpole, cheetah, humanoid plus walker, pendulum,
-acrobot, hopper and reacher (first SURVEY.md 8f row); the remaining reference
+acrobot, hopper, reacher and point_mass (first SURVEY.md 8f row); the remaining reference
 domains need primitives that are not implemented yet.
 
 Batched use: `environment_kwargs={'batch_size': 8192, 'device': 0,
@@ -22,6 +22,7 @@ from dm_control_amd.suite import cheetah
 from dm_control_amd.suite import hopper
 from dm_control_amd.suite import humanoid
 from dm_control_amd.suite import pendulum
+from dm_control_amd.suite import point_mass
 from dm_control_amd.suite import reacher
 from dm_control_amd.suite import walker
 

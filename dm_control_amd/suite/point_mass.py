@@ -1,0 +1,106 @@
+"""Point-mass domain (cf. /root/reference/dm_control/suite/point_mass.py).
+
+The "hard" task makes every control actuate a random direction in the plane by
+rewriting `model.wrap_prm` (the coefficients of the two fixed tendons) each
+episode; here those four numbers are per-instance task data in HBM.
+"""
+
+import numpy as np
+
+from dm_control_amd import codegen
+from dm_control_amd import engine
+from dm_control_amd import wrapper
+from dm_control_amd.rl import control
+from dm_control_amd.suite import base
+from dm_control_amd.suite import common
+from dm_control_amd.suite import randomizers
+from dm_control_amd.utils import containers
+
+_DEFAULT_TIME_LIMIT = 20
+SUITE = containers.TaggedTasks()
+
+
+def get_model_and_assets():
+  return common.read_model('point_mass.xml'), common.ASSETS
+
+
+def _make(randomize_gains, time_limit, random, environment_kwargs):
+  phys_kw, task_kw, env_kw = common.split_kwargs(environment_kwargs)
+  physics = Physics.from_xml_string(*get_model_and_assets(), **phys_kw)
+  task = PointMass(randomize_gains=randomize_gains, random=random, **task_kw)
+  physics.set_task_params(iparam=1 if randomize_gains else 0)
+  return control.Environment(physics, task, time_limit=time_limit, **env_kw)
+
+
+@SUITE.add('benchmarking', 'easy')
+def easy(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None):
+  """Returns the easy point_mass task (point_mass.py:39-46)."""
+  return _make(False, time_limit, random, environment_kwargs)
+
+
+@SUITE.add()
+def hard(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None):
+  """Returns the hard point_mass task (point_mass.py:49-56)."""
+  return _make(True, time_limit, random, environment_kwargs)
+
+
+class Physics(engine.Physics):
+  """Physics with the point-mass helpers (point_mass.py:59-70).
+
+  Fused observation layout: [qpos, qvel].
+  """
+
+  _TASK = codegen.TASK_POINTMASS
+
+  def mass_to_target(self):
+    m = self.model
+    xpos = np.asarray(self.data.xpos).reshape(-1, m.nbody, 3)
+    target = m.geom_pos[m.name2id('target', 'geom')]
+    v = target - xpos[:, m.name2id('pointmass', 'body')]
+    return v[0] if self.batch_size is None else v
+
+  def mass_to_target_dist(self):
+    return np.linalg.norm(self.mass_to_target(), axis=-1)
+
+  def actuation_directions(self):
+    """[B, 2, 2]: the joint-space direction each control pulls along."""
+    t = self.batch.read(wrapper.FIELD_TASKDATA).T.astype(np.float64)
+    t = t.reshape(-1, 2, 2)
+    return t[0] if self.batch_size is None else t
+
+
+class PointMass(base.Task):
+  """Reach the target with a smooth reward (point_mass.py:73-130)."""
+
+  def __init__(self, randomize_gains, random=None, device_init=False):
+    self._randomize_gains = randomize_gains
+    super().__init__(random=random, device_init=device_init)
+
+  def initialize_episode(self, physics):
+    if self._device_init:
+      physics.batch.init_episode(self.device_seed())
+    else:
+      qpos, gains = [], []
+      for rs in self.streams(physics):
+        q = physics.model.qpos0.copy()
+        randomizers.randomize_limited_and_rotational_joints(physics.model, q, rs)
+        qpos.append(q)
+        if self._randomize_gains:       # point_mass.py:103-113, same draw order
+          dir1 = rs.randn(2)
+          dir1 /= np.linalg.norm(dir1)
+          parallel = True
+          while parallel:
+            dir2 = rs.randn(2)
+            dir2 /= np.linalg.norm(dir2)
+            parallel = abs(np.dot(dir1, dir2)) > 0.9
+          gains.append(np.concatenate([dir1, dir2]))
+      qpos = np.array(qpos)
+      physics.data.qpos[:] = qpos[0] if physics.batch_size is None else qpos
+      if self._randomize_gains:
+        physics.batch.write(wrapper.FIELD_TASKDATA, np.array(gains).T)
+    super().initialize_episode(physics)
+
+  def get_observation(self, physics):
+    m = physics.model
+    return self._obs_dict(physics, [('position', m.nq, False),
+                                    ('velocity', m.nv, False)])

@@ -121,10 +121,10 @@ def rewards_golden():
 
 def tasks_golden():
   from dm_control.suite import (acrobot, cartpole, cheetah, hopper, humanoid,
-                                pendulum, reacher, walker)
+                                pendulum, point_mass, reacher, walker)
   rs = np.random.RandomState(1)
   out = {'cartpole': [], 'cheetah': [], 'humanoid': [], 'walker': [],
-         'pendulum': [], 'acrobot': [], 'hopper': [], 'reacher': []}
+         'pendulum': [], 'acrobot': [], 'hopper': [], 'reacher': [], 'point_mass': []}
 
   for _ in range(24):
     x, cos, ctrl = rs.uniform(-2, 2), rs.uniform(-1, 1), rs.uniform(-1.5, 1.5)
@@ -251,6 +251,24 @@ def tasks_golden():
       rec['reward_%g' % size] = float(
           reacher.Reacher(target_size=size, random=0).get_reward(P()))
     out['reacher'].append(rec)
+
+  class _TargetSize:   # named.model.geom_size['target', 0]
+    def __getitem__(self, key):
+      assert key == ('target', 0)
+      return 0.015
+  for _ in range(24):
+    dist = rs.uniform(0, 0.04) if rs.rand() < 0.6 else rs.uniform(0, 0.4)
+    ctrl = rs.uniform(-1.2, 1.2, 2)
+
+    class P(point_mass.Physics):
+      named = types.SimpleNamespace(model=types.SimpleNamespace(
+          geom_size=_TargetSize()))
+      def mass_to_target_dist(self): return dist
+      def control(self): return ctrl
+    out['point_mass'].append(dict(
+        dist=dist, ctrl=ctrl.tolist(),
+        reward=float(point_mass.PointMass(randomize_gains=False,
+                                          random=0).get_reward(P()))))
   return out
 
 

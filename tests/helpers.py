@@ -10,11 +10,13 @@ from dm_control_amd.mjcf import compiler
 TASKS = {'cartpole': codegen.TASK_CARTPOLE, 'cheetah': codegen.TASK_CHEETAH,
          'humanoid': codegen.TASK_HUMANOID, 'walker': codegen.TASK_WALKER,
          'pendulum': codegen.TASK_PENDULUM, 'acrobot': codegen.TASK_ACROBOT,
-         'hopper': codegen.TASK_HOPPER, 'reacher': codegen.TASK_REACHER}
+         'hopper': codegen.TASK_HOPPER, 'reacher': codegen.TASK_REACHER,
+         'point_mass': codegen.TASK_POINTMASS}
 # build mode per suite model (humanoid: see suite/humanoid.py)
 MODES = {'cartpole': 'auto', 'cheetah': 'auto', 'humanoid': 'coop',
          'walker': 'auto', 'pendulum': 'auto', 'acrobot': 'auto',
-         'hopper': 'auto', 'reacher': 'auto'}
+         'hopper': 'auto', 'reacher': 'auto',
+         'point_mass': 'auto'}
 
 
 def model_xml(name):
@@ -52,6 +54,10 @@ def initial_states(model, name, nenv, seed):
     qpos[:, 1] = rs.uniform(-0.16, -0.04, nenv)   # rootz: foot near / into the floor
     qpos[:, 2] = rs.uniform(-0.2, 0.2, nenv)
     qvel[:] = 0.5*rs.randn(nenv, model.nv)
+  elif name == 'point_mass':
+    qpos[:] = rs.uniform(-0.29, 0.29, (nenv, 2))   # incl. at the joint limits
+    qpos[::5] *= 1.02
+    qvel[:] = 0.3*rs.randn(nenv, 2)
   elif name == 'reacher':
     qpos[:, 0] = rs.uniform(-np.pi, np.pi, nenv)
     qpos[:, 1] = rs.uniform(-2.7, 2.7, nenv)

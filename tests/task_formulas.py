@@ -94,3 +94,12 @@ def hopper_reward(height, speed, ctrl, hopping):
 def reacher_reward(finger_to_target_dist, target_size, finger_size=0.01):
   """suite/reacher.py:118-120."""
   return rewards.tolerance(finger_to_target_dist, (0, target_size + finger_size))
+
+
+def point_mass_reward(mass_to_target_dist, ctrl, target_size=0.015):
+  """suite/point_mass.py:122-130."""
+  near = rewards.tolerance(mass_to_target_dist, bounds=(0, target_size),
+                           margin=target_size)
+  control_reward = rewards.tolerance(np.asarray(ctrl), margin=1, value_at_margin=0,
+                                     sigmoid='quadratic').mean()
+  return near*(control_reward + 4)/5

@@ -17,7 +17,8 @@ REF_SUITE = '/root/reference/dm_control/suite'
 
 
 @pytest.mark.parametrize('name', ['cartpole', 'cheetah', 'humanoid', 'walker',
-                                  'pendulum', 'acrobot', 'hopper', 'reacher'])
+                                  'pendulum', 'acrobot', 'hopper', 'reacher',
+                                  'point_mass'])
 def test_in_tree_models_compile_like_the_reference_files(name):
   """The in-tree parameter tables (suite/models/*.py) give the same compiled
   model, names and ordering included, as the reference's MJCF files (which also
@@ -87,9 +88,40 @@ def test_defaults_classes_and_freejoint():
     hu.name2id('nope', 'joint')
 
 
+def test_fixed_tendons_and_tendon_actuators():
+  """point_mass.xml: two fixed tendons over the sliders, motors on tendons."""
+  pm = helpers.load_model('point_mass')
+  assert (pm.ntendon, pm.nwrap) == (2, 4)
+  assert pm.tendon_adr.tolist() == [0, 2] and pm.tendon_num.tolist() == [2, 2]
+  assert pm.wrap_objid.tolist() == [0, 1, 0, 1]
+  assert pm.wrap_prm.tolist() == [1, 0, 0, 1]
+  assert pm.actuator_trntype.tolist() == [mdl.TRN_TENDON]*2
+  assert pm.actuator_trnid.tolist() == [0, 1]
+  # oracle: control 0 accelerates x only; with swapped coefficients y only
+  d = oracle.OracleData(oracle.OracleModel(pm))
+  d.ctrl[:] = [1, 0]
+  d.step1()
+  d.physics_step()
+  assert d.qvel[0] > 0 and d.qvel[1] == 0
+  import copy
+  sw = copy.copy(pm)
+  sw.wrap_prm = np.array([0.0, 1, 1, 0])
+  d = oracle.OracleData(oracle.OracleModel(sw))
+  d.ctrl[:] = [1, 0]
+  d.step1()
+  d.physics_step()
+  assert d.qvel[1] > 0 and d.qvel[0] == 0
+
+
 def test_unsupported_features_raise():
   with pytest.raises(compiler.CompileError):
-    compiler.from_xml_string('<mujoco><worldbody/><tendon><fixed/></tendon></mujoco>')
+    compiler.from_xml_string(      # spatial tendons are not implemented
+        '<mujoco><worldbody/><tendon><spatial/></tendon></mujoco>')
+  with pytest.raises(compiler.CompileError):
+    compiler.from_xml_string(      # nor are tendon springs / dampers / limits
+        '<mujoco><worldbody><body><joint name="j"/><geom size="1"/></body>'
+        '</worldbody><tendon><fixed stiffness="2"><joint joint="j" coef="1"/>'
+        '</fixed></tendon></mujoco>')
   with pytest.raises(compiler.CompileError):
     compiler.from_xml_string(
         '<mujoco><worldbody><body><joint frictionloss="1"/><geom size="1"/>'

@@ -99,7 +99,8 @@ def _teacher_forced(name, precision, nenv, steps, nsub, lds_budget=None,
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
                                        ('humanoid', 5), ('walker', 10),
                                        ('pendulum', 1), ('acrobot', 1),
-                                       ('hopper', 4), ('reacher', 1)])
+                                       ('hopper', 4), ('reacher', 1),
+                                       ('point_mass', 1)])
 def test_fp64_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f64', nenv=64, steps=12, nsub=nsub)
   assert e.max() <= 1e-9, e.max()
@@ -108,7 +109,8 @@ def test_fp64_build_matches_oracle_per_step(name, nsub):
 @pytest.mark.parametrize('name,nsub', [('cartpole', 1), ('cheetah', 1),
                                        ('humanoid', 5), ('walker', 10),
                                        ('pendulum', 1), ('acrobot', 1),
-                                       ('hopper', 4), ('reacher', 1)])
+                                       ('hopper', 4), ('reacher', 1),
+                                       ('point_mass', 1)])
 def test_fp32_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f32', nenv=128, steps=12, nsub=nsub)
   assert np.median(e) <= 2e-6, np.median(e)
@@ -118,7 +120,8 @@ def test_fp32_build_matches_oracle_per_step(name, nsub):
 
 @pytest.mark.parametrize('name,nsub,group', [
     ('cartpole', 1, 64), ('cheetah', 1, 64), ('walker', 10, 64),
-    ('hopper', 4, 64), ('cheetah', 1, 32), ('humanoid', 5, 32)])
+    ('hopper', 4, 64), ('point_mass', 1, 64), ('cheetah', 1, 32),
+    ('humanoid', 5, 32)])
 def test_several_lanes_per_env_build_matches_oracle(name, nsub, group):
   """csrc/dmc_coop.hip (mode='coop': a group of lanes per env, working set in
   LDS) on models whose default is the one-lane kernel, and with two envs per
@@ -337,7 +340,8 @@ def test_fused_task_outputs_match_reference_formulas():
                              ('acrobot', 'swingup', 64),
                              ('acrobot', 'swingup_sparse', 64),
                              ('hopper', 'stand', 32), ('hopper', 'hop', 32),
-                             ('reacher', 'easy', 64), ('reacher', 'hard', 64)):
+                             ('reacher', 'easy', 64), ('reacher', 'hard', 64),
+                             ('point_mass', 'easy', 64)):
     env = suite.load(domain, task, task_kwargs={'random': 4},
                      environment_kwargs={'batch_size': nenv})
     physics = env.physics
@@ -374,6 +378,10 @@ def test_fused_task_outputs_match_reference_formulas():
                                    xmat[i, 1:][:, [0, 2]].ravel(), atol=1e-6)
         np.testing.assert_allclose(ts.observation['height'][i],
                                    xpos[i, torso, 2])
+      elif domain == 'point_mass':
+        dist = np.linalg.norm(np.array([0, 0, .01]) - xpos[i, 1])
+        want = task_formulas.point_mass_reward(dist, ctrl[i])
+        np.testing.assert_allclose(physics.mass_to_target_dist()[i], dist, atol=1e-7)
       elif domain == 'reacher':
         m = physics.model
         finger = xpos[i, m.name2id('finger', 'body'), :2]
@@ -596,6 +604,55 @@ def test_per_instance_task_data_write_and_device_init():
   ang = np.arctan2(*dev.physics.target_position().T)
   assert abs(ang.mean()) < 0.15 and ang.std() > 1.5
   dev.physics.free()
+
+
+def test_point_mass_hard_per_instance_actuation_directions():
+  """point_mass 'hard' redraws the tendon coefficients (model.wrap_prm in the
+  reference) per episode: each instance is stepped against an oracle model
+  compiled with that instance's coefficients; the device-side initialiser
+  draws unit directions that are not too parallel."""
+  import copy
+  env = suite.load('point_mass', 'hard', task_kwargs={'random': 2},
+                   environment_kwargs={'batch_size': 8, 'precision': 'f64'})
+  env.reset()
+  physics = env.physics
+  dirs = physics.actuation_directions()
+  assert dirs.shape == (8, 2, 2)
+  np.testing.assert_allclose(np.linalg.norm(dirs, axis=2), 1, atol=1e-12)
+  assert np.all(np.abs(np.einsum('ek,ek->e', dirs[:, 0], dirs[:, 1])) <= 0.9)
+  assert np.abs(dirs[0] - np.eye(2)).max() > 1e-3
+  q0 = np.asarray(physics.data.qpos).copy()
+  datas = []
+  for i in range(8):
+    mi = copy.copy(physics.model)
+    mi.wrap_prm = dirs[i].ravel().copy()
+    d = oracle.OracleData(oracle.OracleModel(mi))
+    d.qpos[:] = q0[i]
+    d.step1()
+    datas.append(d)
+  rs = np.random.RandomState(0)
+  for _ in range(25):
+    a = rs.uniform(-1, 1, (8, 2))
+    env.step(a)
+    for i, d in enumerate(datas):
+      d.ctrl[:] = a[i]
+      d.physics_step()
+  got = np.asarray(physics.data.qpos)
+  np.testing.assert_allclose(got, [d.qpos for d in datas], atol=1e-12)
+  physics.free()
+  dev = suite.load('point_mass', 'hard', task_kwargs={'random': 2},
+                   environment_kwargs={'batch_size': 2048, 'device_init': True})
+  dev.reset()
+  dd = dev.physics.actuation_directions()
+  np.testing.assert_allclose(np.linalg.norm(dd, axis=2), 1, atol=1e-5)
+  assert np.all(np.abs(np.einsum('ek,ek->e', dd[:, 0], dd[:, 1])) <= 0.9 + 1e-5)
+  assert np.abs(dd[:, 0].mean(axis=0)).max() < 0.08      # isotropic
+  easy = suite.load('point_mass', 'easy', environment_kwargs={'batch_size': 4})
+  easy.reset()
+  np.testing.assert_array_equal(easy.physics.actuation_directions(),
+                                np.tile(np.eye(2), (4, 1, 1)))
+  for e in (dev, easy):
+    e.physics.free()
 
 
 def test_c_abi_argument_errors():
