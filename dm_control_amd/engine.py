@@ -244,14 +244,15 @@ class Physics(_control.Physics):
 
   _TASK = codegen.TASK_NONE   # domain subclasses select the fused task
   _BUILD_MODE = 'auto'        # see build.build_model
-  # Batches up to this size use the several-lanes-per-env kernel
-  # (build mode "coop") when the mode is "auto": one env per lane needs >= 64
-  # envs per CU to fill the chip, a group per env fills it at 4 envs per CU.
-  # Measured cross-over per domain; 0 = never.
-  _COOP_MAX_BATCH = 0
+  # When the mode is "auto", batches up to `max_batch` use the several-lanes-
+  # per-env kernel (build mode "coop") with `group` lanes per env: one env per
+  # lane needs >= 64 envs per CU to fill the chip, one env per wavefront fills
+  # it at 4 per CU, two envs per wavefront at 8.  ((max_batch, group), ...) in
+  # increasing max_batch; measured cross-overs per domain.
+  _COOP_POLICY = ()
 
   def __init__(self, model, batch_size=None, device=0, precision='f32',
-               task=None, ncon_max=None, build_mode=None):
+               task=None, ncon_max=None, build_mode=None, group=None):
     self.model = model
     self._squeeze = batch_size is None
     self._batch_size = 1 if batch_size is None else int(batch_size)
@@ -267,12 +268,15 @@ class Physics(_control.Physics):
     self._profile_seconds = 0.0
     self._profile_calls = 0
     self._build_mode = build_mode or self._BUILD_MODE
-    if (build_mode is None and self._build_mode == 'auto' and
-        self._batch_size <= self._COOP_MAX_BATCH):
-      self._build_mode = 'coop'
+    self._group = group or 64
+    if build_mode is None and self._build_mode == 'auto':
+      for max_batch, lanes in self._COOP_POLICY:
+        if self._batch_size <= max_batch:
+          self._build_mode, self._group = 'coop', lanes
+          break
     path = build.build_model(
         model, self._task_id, precision, ncon_max, mode=self._build_mode,
-        lds_budget=build.lds_budget_for(self._batch_size))
+        lds_budget=build.lds_budget_for(self._batch_size), group=self._group)
     self._hip_model = wrapper.HipModel(path, device)
     self._batch = wrapper.HipBatch(self._hip_model, self._batch_size)
     self.data = _Data(self)
@@ -460,7 +464,7 @@ class Physics(_control.Physics):
     Physics.__init__(new, self.model,
                      None if self._squeeze else self._batch_size,
                      self._device, self._precision, self._task_id,
-                     self._ncon_max, self._build_mode)
+                     self._ncon_max, self._build_mode, self._group)
     new._batch.copy_state_from(self._batch)
     new._warn_seen = self._warn_seen.copy()
     new._dirty = self._dirty

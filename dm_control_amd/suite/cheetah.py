@@ -32,8 +32,8 @@ def run(time_limit=_DEFAULT_TIME_LIMIT, random=None, environment_kwargs=None):
 class Physics(engine.Physics):
 
   _TASK = codegen.TASK_CHEETAH
-  # several lanes per env up to this batch size (measured cross-over)
-  _COOP_MAX_BATCH = 2048
+  # one env per wavefront up to 2048 envs (measured cross-over)
+  _COOP_POLICY = ((2048, 64),)
 
   def speed(self):
     """Horizontal speed of the Cheetah (cheetah.py:55-57)."""

@@ -50,8 +50,8 @@ class Physics(engine.Physics):
   """
 
   _TASK = codegen.TASK_HOPPER
-  # several lanes per env up to this batch size (same cross-over as the walker)
-  _COOP_MAX_BATCH = 8192
+  # one env per wavefront up to 2048 envs, two up to 4096 (measured cross-overs)
+  _COOP_POLICY = ((2048, 64), (4096, 32))
 
   def height(self):
     """Height of the torso's centre of mass above the foot's."""

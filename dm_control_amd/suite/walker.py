@@ -49,8 +49,8 @@ class Physics(engine.Physics):
   """Physics with the Walker helpers (walker.py:79-100)."""
 
   _TASK = codegen.TASK_WALKER
-  # several lanes per env up to this batch size (measured cross-over)
-  _COOP_MAX_BATCH = 8192
+  # one env per wavefront up to 2048 envs, two up to 8192 (measured cross-overs)
+  _COOP_POLICY = ((2048, 64), (8192, 32))
 
   def torso_upright(self):
     return self.named.data.xmat['torso', 'zz']
