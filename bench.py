@@ -73,8 +73,14 @@ def usable_cores():
   return n
 
 
-def cpu_baseline(domain, task, nsub, budget_s=12.0):
-  """Times the fp64 oracle (OpenMP over envs) on a bounded sample."""
+def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None):
+  """Times the fp64 oracle (OpenMP over envs) on a bounded sample.
+
+  With `gpu_batch` (the benchmarked batch) the same leg also reports the
+  second half of BASELINE's metric, "qpos rel-err vs CPU mj_step": 64 states
+  taken from the benchmarked batch are stepped by the benchmarked code object
+  and by the oracle, teacher-forced, under the same controls.
+  """
   from dm_control_amd import suite as _suite  # host logic only (model compile)
   from dm_control_amd.mjcf import compiler
   from oracle import oracle
@@ -113,12 +119,56 @@ def cpu_baseline(domain, task, nsub, budget_s=12.0):
       ctrl = rs.uniform(-1, 1, (nenv, model.nu))
     oracle.batch_step(om, datas, ctrl, nsub, cores)
   dt = time.time() - t0
-  return {
+  out = {
       'value': nenv*reps/dt, 'unit': 'env-steps/s', 'cores': int(used),
       'kind': 'port',
       'sample': '%s-%s: %d envs x %d control steps (%d physics steps each), '
                 'fp64 C restatement of mj_step, OpenMP over envs, %.1f s'
                 % (domain, task, nenv, reps, nsub, dt)}
+  if gpu_batch is not None:
+    out['qpos_rel_err'] = _rel_err_sample(gpu_batch, om, oracle, nsub)
+  return out
+
+
+def _rel_err_sample(gpu_batch, om, oracle, nsub, nenv=64, steps=20):
+  """max|q_gpu - q_cpu| / max(1, max|q_cpu|) per env and control step."""
+  from dm_control_amd import wrapper
+  W = wrapper
+  model = om.model
+  q0 = gpu_batch.read(W.FIELD_QPOS).T[:nenv].astype(np.float64)
+  v0 = gpu_batch.read(W.FIELD_QVEL).T[:nenv].astype(np.float64)
+  nenv = len(q0)
+  hb = W.HipBatch(gpu_batch.model, nenv)       # same code object as the bench
+  if model.nu and gpu_batch.model.info.ntaskdata:
+    hb.write(W.FIELD_TASKDATA, gpu_batch.read(W.FIELD_TASKDATA)[:, :nenv])
+  datas = [oracle.OracleData(om) for _ in range(nenv)]
+  for i, d in enumerate(datas):
+    d.qpos[:] = q0[i]
+    d.qvel[:] = v0[i]
+    d.step1()
+  rs = np.random.RandomState(1)
+  errs = []
+  for _ in range(steps):
+    oq = np.array([d.qpos.copy() for d in datas])
+    ov = np.array([d.qvel.copy() for d in datas])
+    ow = np.array([d.qacc_warmstart.copy() for d in datas])
+    hb.set_state(oq.T, ov.T, ow.T)
+    ctrl = rs.uniform(-1, 1, (nenv, model.nu))
+    hb.step_host(ctrl, nsub)
+    q = hb.read(W.FIELD_QPOS).T.astype(np.float64)
+    for i, d in enumerate(datas):
+      d.ctrl[:] = ctrl[i]
+      for _ in range(nsub):
+        d.physics_step()
+    nq = np.array([d.qpos.copy() for d in datas])
+    errs.append(np.abs(q - nq).max(axis=1)/np.maximum(1, np.abs(nq).max(axis=1)))
+  hb.free()
+  e = np.concatenate(errs)
+  return {'median': float(np.median(e)), 'p99': float(np.percentile(e, 99)),
+          'max': float(e.max()),
+          'sample': 'teacher-forced, %d envs from the benchmarked batch x %d '
+                    'control steps, same code object, U(-1,1) controls'
+                    % (nenv, steps)}
 
 
 def main():
@@ -254,7 +304,8 @@ def main():
         'envs_with_warnings': int((warn != 0).sum()),
     }
     if world == 1 and not args.no_cpu_baseline:
-      line['cpu_baseline'] = cpu_baseline(args.domain, args.task, nsub)
+      line['cpu_baseline'] = cpu_baseline(args.domain, args.task, nsub,
+                                          gpu_batch=batch)
     print(json.dumps(line))
   if distributed:
     dist.destroy_process_group()
