@@ -422,6 +422,20 @@ int dmc_batch_step(dmc_batch* b, const void* ctrl, long long stride_k,
   return 0;
 }
 
+int dmc_batch_step_n(dmc_batch* b, const void* ctrl, long long stride_k,
+                     long long stride_env, long long stride_t, int nsteps,
+                     int nsub, int want_outputs) {
+  if (!b) return fail("null batch");
+  if (!ctrl) return fail("dmc_batch_step_n: device controls required");
+  if (nsteps < 0) return fail("nsteps must be >= 0");
+  const size_t rs = (size_t)b->model->info.real_size;
+  for (int t = 0; t < nsteps; t++)
+    if (dmc_batch_step(b, (const char*)ctrl + (size_t)t*(size_t)stride_t*rs, stride_k,
+                       stride_env, 1, nsub, want_outputs))
+      return -1;
+  return 0;
+}
+
 size_t dmc_batch_field_bytes(const dmc_batch* b, int field) {
   if (!b || field < 0 || field >= DMC_FIELD_COUNT) return 0;
   return b->bytes[field];

@@ -1112,7 +1112,7 @@ struct Coop {
       real lo = 0, hi = 0, a = -p0.d0/p0.d1;
       bool have_hi = false;
       const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
-      for (int it = 0; it < (DMC_F32_RULES ? 20 : 50); it++) {
+      for (int it = 0; it < DMC_LS_MAXIT; it++) {
         ls_eval(p, a, q1, q2);
         if (p.dcost < best.dcost) best = p;
         if (fabs(p.d0) < dtol) break;

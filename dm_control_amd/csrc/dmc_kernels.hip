@@ -51,6 +51,34 @@ typedef float real;
 
 using namespace dmc_model;
 
+// unroll factor of the loops over LDS-resident constraint rows: with one wave
+// per SIMD the only way to overlap a row's LDS round trip is the next row's
+#ifndef DMC_ROW_UNROLL
+#define DMC_ROW_UNROLL 1
+#endif
+#define DMC_STR_(x) #x
+#define DMC_STR(x) DMC_STR_(x)
+#if DMC_ROW_UNROLL > 1
+#define DMC_ROW_UNROLL_PRAGMA _Pragma(DMC_STR(unroll DMC_ROW_UNROLL))
+#else
+#define DMC_ROW_UNROLL_PRAGMA
+#endif
+// Optional scheduling fence (-DDMC_SCHED_FENCE_ON): forces the LDS loads of a
+// constraint row to be issued before their uses.  Measured: no gain on cheetah
+// (0.0698 vs 0.0688 ms -- the row loops are VALU-bound at the per-wave maximum
+// row count, not latency-bound) and a loss on cart-pole (0.019 -> 0.031 ms), so
+// it is off; the row lambdas still load their words first, which is what lets
+// the scheduler batch them when it has the registers.
+#if defined(DMC_SCHED_FENCE_ON) && !defined(DMC_HOST_SHIM)
+#define DMC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define DMC_SCHED_FENCE() do {} while (0)
+#endif
+// line-search evaluations per Newton iteration (experiments may lower it)
+#ifndef DMC_LS_MAXIT
+#define DMC_LS_MAXIT (DMC_F32_RULES ? 20 : 50)
+#endif
+
 #define R(x) ((real)(x))
 #define DEV static __device__ __forceinline__
 #define DEVN static __device__ __forceinline__
@@ -318,6 +346,9 @@ struct Env {
   real subtree_linvel[NBODY*3];
   real touch[NTOUCH > 0 ? NTOUCH : 1];   // touch sensor readings (mj_sensorAcc)
   real taskdata[NTDX];                   // per-instance task parameters
+#ifdef DMC_SOLVER_PROFILE
+  real prof[8];
+#endif
   int ncon, nefc, nefc_limit, iters;
   unsigned warn;
 };
@@ -338,7 +369,16 @@ constexpr int CW = 11;
 constexpr int REC_BYTES = 64*(int)sizeof(real);       // one record word, all lanes
 // big-matrix mode: the factor/Hessian buffer gets LDS first if it leaves room
 constexpr bool MAT_IN_LDS = BIGMAT && NM*REC_BYTES + 4*(RW + CW)*REC_BYTES <= DMC_LDS_BUDGET;
-constexpr int MAT_LDS_WORDS = MAT_IN_LDS ? NM : 0;
+// Small mode with the mass matrix in LDS (-DDMC_M_LDS=1): M is live from the
+// CRBA to the integrator, i.e. across the whole Newton solver, where its NM
+// registers are the difference between a scheduler that can batch the LDS loads
+// of a constraint row and one that must wait for every pair of words.
+#ifndef DMC_M_LDS
+#define DMC_M_LDS 0
+#endif
+constexpr bool M_LDS = !BIGMAT && DMC_M_LDS != 0 && NM > 0 &&
+                       NM*REC_BYTES + 4*(RW + CW)*REC_BYTES <= DMC_LDS_BUDGET;
+constexpr int MAT_LDS_WORDS = (MAT_IN_LDS || M_LDS) ? NM : 0;
 constexpr int REC_BUDGET = DMC_LDS_BUDGET - MAT_LDS_WORDS*REC_BYTES;
 constexpr int LDS_CONS_WANT0 = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
 constexpr int LDS_CONS_WANT = MAT_IN_LDS && LDS_CONS_WANT0 > 6 ? 6 : LDS_CONS_WANT0;
@@ -391,6 +431,7 @@ constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW + MAT_LDS_WORDS > 0
 template <class F>
 static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) {
   const int n1 = nefc < LDS_ROWS ? nefc : LDS_ROWS;
+  DMC_ROW_UNROLL_PRAGMA
   for (int r = 0; r < n1; r++) f(W.lrow(r));
   if (LDS_ROWS < NEFC_MAX)
     for (int r = LDS_ROWS; r < nefc; r++) f(W.grow(r));
@@ -399,7 +440,9 @@ static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) 
 // which storage backs M and the factor/Hessian buffer in this build
 template <bool Big> struct MatSel;
 template <> struct MatSel<false> {
-  static __device__ __forceinline__ RegMat M(Env& E, const Work&) { return RegMat{E.qM}; }
+  static __device__ __forceinline__ auto M(Env& E, const Work& W) {
+    if constexpr (M_LDS) return W.matL_lds(); else return RegMat{E.qM};
+  }
   static __device__ __forceinline__ RegMat L(Env& E, const Work&) { return RegMat{E.qL}; }
 };
 template <> struct MatSel<true> {
@@ -1210,6 +1253,7 @@ DEV void ls_eval(LsPoint& P, real alpha, const Env& E, const Work& W, real q1, r
   real d0 = 2*alpha*q2 + q1, d1 = 2*q2;
   for_rows(W, E.nefc, [&](auto rec) {
     const real x0 = rec.get(ROW_JAR), v = rec.get(ROW_JV), D = rec.get(ROW_D);
+    DMC_SCHED_FENCE();
     const real x = x0 + alpha*v;
     const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
     dcost += R(0.5)*D*(a*a - a0*a0);
@@ -1219,7 +1263,17 @@ DEV void ls_eval(LsPoint& P, real alpha, const Env& E, const Work& W, real q1, r
   P.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
 }
 
+// -DDMC_SOLVER_PROFILE (experiments): 100 MHz time stamps per solver phase,
+// summed per lane, returned through Env::prof and written over the observation
+#ifdef DMC_SOLVER_PROFILE
+#define SPROF(k) do { const long long t_ = wall_clock64(); E.prof[k] += (real)(t_ - tl_); tl_ = t_; } while (0)
+#else
+#define SPROF(k) do {} while (0)
+#endif
 DEV void solve_newton(Env& E, const Work& W, real tol) {
+#ifdef DMC_SOLVER_PROFILE
+  long long tl_ = wall_clock64();
+#endif
   real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], Hreg[MAT_REGS];
   const auto M = Mats::M(E, W);
   // small mode: Hessian in registers; big mode: it reuses the factor buffer
@@ -1228,22 +1282,33 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
   symv(Ma, M, E.qacc);
-  real improvement = 0;
-  bool converged = false;
+  real improvement = 0, alpha_prev = 0;
   int iter = 0;
+  // Every pass over the rows costs an LDS round trip per row that a lone wave
+  // cannot hide, so the passes are fused: (A) applies the previous step to
+  // Jaref, detects active-set changes and accumulates forces, gradient and
+  // Hessian; (B) computes Jv and the line-search quantities at alpha = 0.
   for (;; iter++) {
-    // active set, forces, gradient and Hessian in one pass over the rows
     DMC_UNROLL
     for (int i = 0; i < NM; i++) H.set(i, M.get(i));
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
+    bool changed = false;
     for_rows(W, nefc, [&](auto rec) {
-      const real jar = rec.get(ROW_JAR);
+      real jar = rec.get(ROW_JAR);
+      const real jv = rec.get(ROW_JV), D = rec.get(ROW_D);
+      real row[NVX];
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+      DMC_SCHED_FENCE();
+      if (iter > 0) {
+        const real x1 = jar + alpha_prev*jv;
+        changed |= (jar < 0) != (x1 < 0);
+        rec.set(ROW_JAR, x1);
+        jar = x1;
+      }
       if (jar < 0) {
-        const real D = rec.get(ROW_D), f = -D*jar;
-        real row[NVX];
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+        const real f = -D*jar;
         DMC_UNROLL
         for (int j = 0; j < NV; j++) {
           E.qfrc_constraint[j] += row[j]*f;
@@ -1253,22 +1318,29 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
         }
       }
     });
+    // fp32: after a full step that left the active set unchanged the iterate is
+    // the exact minimiser of the current quadratic piece
+    const bool converged = DMC_F32_RULES && iter > 0 && !changed &&
+                           fabs(alpha_prev - 1) < R(1e-3);
     real gn = 0;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) {
       grad[i] = Ma[i] - E.qfrc_smooth[i] - E.qfrc_constraint[i];
       gn += grad[i]*grad[i];
     }
+    SPROF(0);
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
     chol_factor(H);
     DMC_UNROLL
     for (int i = 0; i < NV; i++) search[i] = -grad[i];
     chol_solve(search, H);
+    SPROF(1);
     real sn = 0;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) sn += search[i]*search[i];
     sn = sqrt(sn);
+    alpha_prev = 0;               // nothing pending if one of the exits below is taken
     if (sn < DMC_MINVAL) break;
     const real gtol = tol*R(0.01)*sn/scale;
     symv(Mv, M, search);
@@ -1278,21 +1350,33 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
       q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
       q2 += R(0.5)*search[i]*Mv[i];
     }
-    for_rows(W, nefc, [&](auto rec) {
-      real sacc = 0;
-      DMC_UNROLL
-      for (int j = 0; j < NV; j++) sacc += rec.get(j)*search[j];
-      rec.set(ROW_JV, sacc);
-    });
-    // exact line search: safeguarded Newton on the directional derivative
+    // pass B: Jv, and the derivatives of the cost along `search` at alpha = 0
     LsPoint p0, p, best;
-    ls_eval(p0, 0, E, W, q1, q2);
+    {
+      real d0 = q1, d1 = 2*q2;
+      for_rows(W, nefc, [&](auto rec) {
+        real row[NVX];
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+        const real x0 = rec.get(ROW_JAR), D = rec.get(ROW_D);
+        DMC_SCHED_FENCE();
+        real sacc = 0;
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) sacc += row[j]*search[j];
+        rec.set(ROW_JV, sacc);
+        if (x0 < 0) { d0 += D*x0*sacc; d1 += D*sacc*sacc; }
+      });
+      p0.alpha = 0; p0.dcost = 0; p0.d0 = d0;
+      p0.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+    }
+    SPROF(2);
+    // exact line search: safeguarded Newton on the directional derivative
     if (!(p0.d0 < 0)) break;
     best = p0;
     real lo = 0, hi = 0, a = -p0.d0/p0.d1;
     bool have_hi = false;
     const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
-    for (int it = 0; it < (DMC_F32_RULES ? 20 : 50); it++) {
+    for (int it = 0; it < DMC_LS_MAXIT; it++) {
       ls_eval(p, a, E, W, q1, q2);
       if (p.dcost < best.dcost) best = p;
       if (fabs(p.d0) < dtol) break;
@@ -1307,20 +1391,13 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
       a = an;
     }
     const real alpha = best.alpha;
+    SPROF(3);
     if (alpha == 0) break;
     improvement = -best.dcost;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) { E.qacc[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
-    bool changed = false;
-    for_rows(W, nefc, [&](auto rec) {
-      const real x0 = rec.get(ROW_JAR);
-      const real x1 = x0 + alpha*rec.get(ROW_JV);
-      changed |= (x0 < 0) != (x1 < 0);
-      rec.set(ROW_JAR, x1);
-    });
-    // qfrc_constraint must be refreshed for the final iterate: flag and let the
-    // next pass over the rows run before leaving
-    if (DMC_F32_RULES && !changed && fabs(alpha - 1) < R(1e-3)) converged = true;
+    alpha_prev = alpha;           // applied to Jaref by the next pass A
+    SPROF(4);
   }
   E.iters = iter;
 }
@@ -1425,13 +1502,14 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
         cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
     }
     for_rows(W, E.nefc, [&](auto rec) {
+      real row[NVX];
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+      const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
+      DMC_SCHED_FENCE();
       real jw = 0, js = 0;
       DMC_UNROLL
-      for (int j = 0; j < NV; j++) {
-        const real v = rec.get(j);
-        jw += v*E.warm[j]; js += v*E.qacc_smooth[j];
-      }
-      const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
+      for (int j = 0; j < NV; j++) { jw += row[j]*E.warm[j]; js += row[j]*E.qacc_smooth[j]; }
       jw -= aref; js -= aref;
       if (jw < 0) cw += R(0.5)*D*jw*jw;
       if (js < 0) cs += R(0.5)*D*js*js;
@@ -1839,6 +1917,9 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   time = a.time[e];
   DMC_UNROLL
   for (int i = 0; i < NTASKDATA; i++) E.taskdata[i] = a.taskdata[sidx(i, e, n, NTDX)];
+#ifdef DMC_SOLVER_PROFILE
+  for (int k = 0; k < 8; k++) E.prof[k] = 0;
+#endif
   E.warn = 0; E.ncon = 0; E.nefc = 0; E.nefc_limit = 0; E.iters = 0;
   DMC_UNROLL
   for (int s = 0; s < (NTOUCH > 0 ? NTOUCH : 1); s++) E.touch[s] = 0;
@@ -1956,6 +2037,10 @@ dmc_step(DmcArgs a) {
 #endif
     store_outputs(E, a, e, true, lds_rows);
   }
+#ifdef DMC_SOLVER_PROFILE
+  __syncthreads();
+  for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
+#endif
   store_env(E, a, e, time);
 }
 

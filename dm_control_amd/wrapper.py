@@ -59,6 +59,7 @@ SIGNATURES = {
     'dmc_batch_init_episode': (_ci, [_vp, ctypes.c_uint64, _ci]),
     'dmc_batch_forward': (_ci, [_vp, _ci]),
     'dmc_batch_step': (_ci, [_vp, _vp, _cll, _cll, _ci, _ci, _ci]),
+    'dmc_batch_step_n': (_ci, [_vp, _vp, _cll, _cll, _cll, _ci, _ci, _ci]),
     'dmc_batch_read': (_ci, [_vp, _ci, _vp, _cs]),
     'dmc_batch_field_bytes': (_cs, [_vp, _ci]),
     'dmc_batch_device_ptr': (_vp, [_vp, _ci]),
@@ -243,6 +244,12 @@ class HipBatch:
     """ctrl_ptr: device address; element (k, env) at k*stride_k+env*stride_env."""
     _check(self._lib.dmc_batch_step(self.ptr, ctrl_ptr, stride_k, stride_env,
                                     1, nsub, int(want_outputs)))
+
+  def step_device_n(self, ctrl_ptr, stride_k, stride_env, stride_t, nsteps,
+                    nsub=1, want_outputs=True):
+    """`nsteps` control steps; step t reads ctrl_ptr + t*stride_t reals."""
+    _check(self._lib.dmc_batch_step_n(self.ptr, ctrl_ptr, stride_k, stride_env,
+                                      stride_t, nsteps, nsub, int(want_outputs)))
 
   def clear_warnings(self):
     _check(self._lib.dmc_batch_clear_warnings(self.ptr))

@@ -134,6 +134,14 @@ int dmc_batch_forward(dmc_batch* batch, int count_contacts);
 int dmc_batch_step(dmc_batch* batch, const void* ctrl, long long stride_k,
                    long long stride_env, int on_device, int nsub,
                    int want_outputs);
+/* `nsteps` control steps back to back on the batch's stream, step t reading
+ * its controls at ctrl + t*stride_t reals (device memory): the n_sub_steps loop
+ * of control.Environment.step (rl/control.py:101-102) over a pre-computed action
+ * sequence (open-loop rollouts, benchmarks) without a host round trip per step;
+ * the observation / reward fields hold those of the last step */
+int dmc_batch_step_n(dmc_batch* batch, const void* ctrl, long long stride_k,
+                     long long stride_env, long long stride_t, int nsteps,
+                     int nsub, int want_outputs);
 
 /* device -> host copy of a whole field (synchronises the batch stream) */
 int dmc_batch_read(dmc_batch* batch, int field, void* dst, size_t bytes);

@@ -655,6 +655,28 @@ def test_point_mass_hard_per_instance_actuation_directions():
     e.physics.free()
 
 
+def test_step_sequence_equals_single_steps():
+  """dmc_batch_step_n (a pre-computed action sequence in device memory, one
+  launch per control step issued from C) gives exactly the single-step path."""
+  import torch
+  model = helpers.load_model('cheetah')
+  qpos, qvel = helpers.initial_states(model, 'cheetah', 512, seed=4)
+  acts = torch.rand(7, 512, model.nu, device='cuda') * 2 - 1
+  out = []
+  for mode in ('single', 'sequence'):
+    hm, hb = _device_batch(model, codegen.TASK_CHEETAH, 'f32', 512)
+    hb.set_state(qpos.T, qvel.T)
+    if mode == 'single':
+      for t in range(7):
+        hb.step_device(acts[t].data_ptr(), 1, model.nu, 1)
+    else:
+      hb.step_device_n(acts.data_ptr(), 1, model.nu, 512*model.nu, 7, 1)
+    out.append((hb.read(W.FIELD_QPOS), hb.read(W.FIELD_OBS), hb.read(W.FIELD_RETURN)))
+    hb.free()
+  for a, b in zip(*out):
+    np.testing.assert_array_equal(a, b)
+
+
 def test_c_abi_argument_errors():
   lib = wrapper.get_lib()
   model = helpers.load_model('cartpole')
