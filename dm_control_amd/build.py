@@ -149,7 +149,7 @@ def lds_budget_for(nenv):
 
 def build_model(model, task=codegen.TASK_NONE, precision='f32',
                 ncon_max=None, force=False, keep_temps=False, extra_flags=None,
-                mode='auto', lds_budget=None, group=64):
+                mode='auto', lds_budget=None, group=64, lanes=64):
   """Generates the constants header for `model` and compiles its kernels.
 
   mode: "unrolled" (static indexing, per-lane state in registers), "rolled"
@@ -168,6 +168,10 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
   if lds_budget is not None and lds_budget != 128*1024:
     extra_flags = tuple(extra_flags) + ('-DDMC_LDS_BUDGET=%d' % lds_budget,)
+  if lanes not in (16, 32, 64):
+    raise ValueError('lanes (envs per workgroup) must be 16, 32 or 64')
+  if lanes != 64 and mode != 'coop':
+    extra_flags = tuple(extra_flags) + ('-DDMC_LANES=%d' % lanes,)
   os.makedirs(_BUILD, exist_ok=True)
   if mode == 'coop':
     # several lanes per env (csrc/dmc_coop.hip): working set in LDS, generic

@@ -77,22 +77,17 @@ struct dmc_batch {
 
 namespace {
 
-// `group` = lanes that advance one env together (1: one env per lane; the
-// several-lanes-per-env kernels of dmc_coop.hip report theirs in dmc_info)
-int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args, int group = 1) {
+int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args, int group = -1) {
   size_t size = sizeof(DmcArgs);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args,
                     HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  // One full wavefront per workgroup.  Measured at 8192 envs (cheetah): 64
-  // lanes/wave on 128 CUs 0.0787 ms, 32 lanes on 256 CUs 0.0828 ms, 16 lanes
-  // 0.152 ms -- thinner waves do not pay.  DMC_BLOCK overrides (experiments).
-  unsigned block = 64;
-  if (const char* env = getenv("DMC_BLOCK")) {
-    const int v = atoi(env);
-    if (v == 16 || v == 32 || v == 64) block = (unsigned)v;
-  }
-  if (group > 1) block = 64;
-  const unsigned per_block = block/(unsigned)(group > 1 ? group : 1);
+  // Workgroup = one wavefront.  `group` lanes advance one env together (the
+  // code object reports its shape in dmc_info); `group` < 0: the task-setup
+  // kernel, always one env per lane of a full wave.
+  const dmc_model_info& mi = b->model->info;
+  unsigned block = 64, per_block = 64;
+  if (group > 1) { per_block = (unsigned)mi.envs_per_block; }
+  else if (group == 1) { block = per_block = (unsigned)mi.envs_per_block; }
   const unsigned grid = (unsigned)((b->nenv + per_block - 1)/per_block);
   HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, b->stream,
                                 nullptr, config));
@@ -196,7 +191,10 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   i.nu = raw[4]; i.nbody = raw[5]; i.nobs = raw[6]; i.nsensordata = raw[7];
   i.ws_per_env = raw[8]; i.task = raw[9]; i.ncon_max = raw[10];
   i.nefc_max = raw[11]; i.integrator = raw[12]; i.npair = raw[13];
-  i.lanes_per_env = raw[14] > 0 && raw[14] < 64 ? 64/raw[14] : 1;
+  // raw[14] envs per workgroup, raw[17] threads per workgroup: one env per lane
+  // (64, 32 or 16 envs in a 64-wide wave) or a group of lanes per env
+  i.envs_per_block = raw[14] > 0 ? raw[14] : 64;
+  i.lanes_per_env = raw[17] > i.envs_per_block ? raw[17]/i.envs_per_block : 1;
   i.env_major = raw[15] != 0;
   i.ntaskdata = raw[16];
   *out = m;

@@ -1515,4 +1515,5 @@ extern "C" __device__ const int dmc_info[20] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     1 /*workspace reals per env: none, everything is in LDS*/, TASK, NCON_MAX, NEFC_MAX,
     INTEGRATOR, NPAIR, EPB /*envs per 64-lane workgroup*/,
-    DMC_ENV_MAJOR /*state fields are [env][k]*/, NTASKDATA, 0, 0, 0};
+    DMC_ENV_MAJOR /*state fields are [env][k]*/, NTASKDATA, 64 /*threads per workgroup*/,
+    0, 0};

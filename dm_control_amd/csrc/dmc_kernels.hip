@@ -84,6 +84,17 @@ using namespace dmc_model;
 #define DEVN static __device__ __forceinline__
 
 constexpr int NM = NV*(NV + 1)/2;      // packed lower triangle
+// Envs (= active lanes) per workgroup.  A wave costs what its busiest lane costs
+// (rows x Newton iterations), so while the batch leaves SIMDs idle anyway
+// (8192 envs = 128 full waves on 1024 SIMDs) thinner workgroups -- 32 or 16
+// envs in a 64-wide wave -- shorten the launch: the maximum over 16 envs is
+// smaller than over 64.  The LDS record stride follows, so four 16-env
+// workgroups need the LDS of one 64-env workgroup.
+#ifndef DMC_LANES
+#define DMC_LANES 64
+#endif
+constexpr int LANES = DMC_LANES;
+static_assert(LANES == 16 || LANES == 32 || LANES == 64, "envs per workgroup");
 // Optional "big matrix" storage (-DDMC_BIGMAT=1): M in the HBM workspace, its
 // factor / the Newton Hessian in one LDS-resident (fp32) or HBM-resident (fp64)
 // buffer instead of per-lane registers.  Measured on the 27-dof humanoid it is
@@ -256,8 +267,8 @@ struct RegMat {
 };
 struct LdsMat {
   real* p;
-  __device__ __forceinline__ real get(int i) const { return p[i*64]; }
-  __device__ __forceinline__ void set(int i, real x) const { p[i*64] = x; }
+  __device__ __forceinline__ real get(int i) const { return p[i*LANES]; }
+  __device__ __forceinline__ void set(int i, real x) const { p[i*LANES] = x; }
 };
 struct GlbMat {
   real* p; long long n;
@@ -366,7 +377,7 @@ constexpr int CW = 11;
 #ifndef DMC_CON_LDS
 #define DMC_CON_LDS 12
 #endif
-constexpr int REC_BYTES = 64*(int)sizeof(real);       // one record word, all lanes
+constexpr int REC_BYTES = LANES*(int)sizeof(real);    // one record word, all lanes
 // big-matrix mode: the factor/Hessian buffer gets LDS first if it leaves room
 constexpr bool MAT_IN_LDS = BIGMAT && NM*REC_BYTES + 4*(RW + CW)*REC_BYTES <= DMC_LDS_BUDGET;
 // Small mode with the mass matrix in LDS (-DDMC_M_LDS=1): M is live from the
@@ -393,8 +404,8 @@ enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3 };
 
 struct LdsRow {
   real* p;
-  __device__ __forceinline__ real get(int k) const { return p[k*64]; }
-  __device__ __forceinline__ void set(int k, real v) const { p[k*64] = v; }
+  __device__ __forceinline__ real get(int k) const { return p[k*LANES]; }
+  __device__ __forceinline__ void set(int k, real v) const { p[k*LANES] = v; }
 };
 struct GlbRow {
   real* p; long long n;
@@ -412,21 +423,21 @@ struct Work {
   real* glb;   // workspace base + env
   long long nenv;
   __device__ __forceinline__ GlbMat matM() const { return GlbMat{glb + (long long)WS_MAT_M*nenv, nenv}; }
-  __device__ __forceinline__ LdsMat matL_lds() const { return LdsMat{lds + (LDS_ROWS*RW + LDS_CONS*CW)*64}; }
+  __device__ __forceinline__ LdsMat matL_lds() const { return LdsMat{lds + (LDS_ROWS*RW + LDS_CONS*CW)*LANES}; }
   __device__ __forceinline__ GlbMat matL_glb() const { return GlbMat{glb + (long long)WS_MAT_L*nenv, nenv}; }
-  __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*64}; }
+  __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*LANES}; }
   __device__ __forceinline__ GlbRow grow(int r) const {
     return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
   }
   __device__ __forceinline__ LdsRow lcon(int k) const {
-    return LdsRow{lds + (LDS_ROWS*RW + k*CW)*64};
+    return LdsRow{lds + (LDS_ROWS*RW + k*CW)*LANES};
   }
   __device__ __forceinline__ GlbRow gcon(int k) const {
     return GlbRow{glb + ((long long)GLB_ROWS*RW + (long long)(k - LDS_CONS)*CW)*nenv, nenv};
   }
 };
 constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW + MAT_LDS_WORDS > 0
-                           ? LDS_ROWS*RW + LDS_CONS*CW + MAT_LDS_WORDS : 1)*64;
+                           ? LDS_ROWS*RW + LDS_CONS*CW + MAT_LDS_WORDS : 1)*LANES;
 // f(row handle) for rows [0, nefc): LDS tier first, then the HBM tier
 template <class F>
 static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) {
@@ -1939,7 +1950,7 @@ DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
 // envs of a workgroup are one contiguous chunk, so they are transposed through
 // LDS (the solver's row store is dead by now) and written as full wave-wide
 // coalesced stores.  Other layouts (explicit strides) are written directly.
-constexpr bool OBS_STAGE_FITS = LDS_WORDS >= 64*(NOBS > 0 ? NOBS : 1);
+constexpr bool OBS_STAGE_FITS = LDS_WORDS >= LANES*(NOBS > 0 ? NOBS : 1);
 
 DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
                        real* lds_base) {
@@ -1949,7 +1960,7 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
   if (OBS_STAGE_FITS && a.obs_sk == 1 && a.obs_se == NOBS) {
     const int lane = threadIdx.x;
     DMC_UNROLL
-    for (int k = 0; k < NOBS; k++) lds_base[k*64 + lane] = obs[k];
+    for (int k = 0; k < NOBS; k++) lds_base[k*LANES + lane] = obs[k];
     __syncthreads();
     const long long base = (long long)blockIdx.x*blockDim.x;
     const long long left = n - base;
@@ -1957,7 +1968,7 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
     real* out = a.obs + base*NOBS;
     // lanes 0..nvalid-1 are exactly the active ones of a partial last block
     for (int w = lane; w < nvalid*NOBS; w += nvalid)
-      out[w] = lds_base[(w % NOBS)*64 + w/NOBS];
+      out[w] = lds_base[(w % NOBS)*LANES + w/NOBS];
   } else {
     DMC_UNROLL
     for (int k = 0; k < NOBS; k++)
@@ -1997,7 +2008,7 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
 #ifndef DMC_WAVES_PER_EU
 #define DMC_WAVES_PER_EU 1
 #endif
-extern "C" __global__ void __launch_bounds__(64, DMC_WAVES_PER_EU)
+extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_step(DmcArgs a) {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= a.nenv) return;
@@ -2045,7 +2056,7 @@ dmc_step(DmcArgs a) {
 }
 
 // observation / reward / sensors of the current state (reset, after_reset)
-extern "C" __global__ void __launch_bounds__(64, DMC_WAVES_PER_EU)
+extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_observe(DmcArgs a) {
   const int e = blockIdx.x*blockDim.x + threadIdx.x;
   if (e >= a.nenv) return;
@@ -2192,6 +2203,7 @@ dmc_init_episode(DmcArgs a) {
 extern "C" __device__ const int dmc_info[20] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     (WS_WORDS > 0 ? WS_WORDS : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
-    INTEGRATOR, NPAIR, 64 /*envs per 64-lane workgroup of dmc_step/dmc_observe*/,
-    DMC_ENV_MAJOR /*0: state fields are [k][env]*/, NTASKDATA, 0, 0, 0};
+    INTEGRATOR, NPAIR, LANES /*envs (= threads) per workgroup of dmc_step/dmc_observe*/,
+    DMC_ENV_MAJOR /*0: state fields are [k][env]*/, NTASKDATA,
+    LANES /*threads per workgroup*/, 0, 0};
 #endif

@@ -34,7 +34,7 @@ class ModelInfo(ctypes.Structure):
   _fields_ = [(n, ctypes.c_int) for n in (
       'abi', 'real_size', 'nq', 'nv', 'nu', 'nbody', 'nobs', 'nsensordata',
       'ws_per_env', 'task', 'ncon_max', 'nefc_max', 'integrator', 'npair',
-      'ntaskdata', 'lanes_per_env', 'env_major')]
+      'ntaskdata', 'envs_per_block', 'lanes_per_env', 'env_major')]
 
 
 # every symbol declared in include/dmc_hip.h: (restype, argtypes)
