@@ -21,6 +21,8 @@ for t in range(60):
 its = np.array(its); nefcs = np.array(nefcs)
 print('iters mean %.2f p99 %d max %d | per-wave max mean %.2f | nefc mean %.1f max %d' % (
     its.mean(), np.percentile(its, 99), its.max(), its.reshape(60, -1, 64).max(axis=2).mean(), nefcs.mean(), nefcs.max()))
+print('iters histogram', np.bincount(its.ravel().astype(int))[:30])
+print('per-step max iters', its.max(axis=1)[:20], 'nefc at max', [int(nefcs[t, its[t].argmax()]) for t in range(20)])
 b.sync(); b.timer_start()
 for t in range(100):
   p.set_control(acts[t % 8]); p.step(nsub, check=False)
