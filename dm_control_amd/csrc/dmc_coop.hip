@@ -5,8 +5,9 @@
 // planar models (nv <= ~10), and the wrong one for the 27-dof humanoid: 378
 // mass-matrix entries + 378 Hessian entries + the tree state do not fit one
 // lane's register file, and a 1024-env shard (BASELINE configs[3]) is only 16
-// waves on a 1024-SIMD chip.  Here a GROUP of G lanes (G = 32: two envs per
-// wave) advances one environment together:
+// waves on a 1024-SIMD chip.  Here a GROUP of G lanes (default G = 64: one env
+// per wavefront; 32 = two envs per wavefront is used for mid-size walker /
+// hopper batches) advances one environment together:
 //
 //   * the env's working set lives in LDS (one region per env, ~35 KB fp32 for
 //     the humanoid incl. all 149 constraint rows -- no HBM workspace at all);
@@ -16,15 +17,19 @@
 //     constraint row; the static geom-pair list is strided over the lanes and
 //     compacted with an ordered prefix sum, so contacts and rows come out in
 //     exactly the order of the one-lane kernel and the CPU oracle;
-//   * Cholesky factor / solves of the nv x nv matrices are cooperative: one
-//     lane per matrix row, one phase per column.
+//   * Cholesky factor / solves of the nv x nv matrices are cooperative: lane
+//     i holds row i in registers, pivot rows travel by v_readlane, finished
+//     4-column panels through LDS (see `rows_chol`);
+//   * the 2-D state fields of these code objects are env-major in HBM
+//     ([env][k], `sidx`), so a group's loads and stores are unit-stride.
 //
 // Lanes of a group communicate through LDS between phases (`gsync`) and
-// through group-wide shuffles for reductions; groups never interact, so the
-// two envs of a wave may take different numbers of Newton iterations.
+// through DPP / readlane reductions; groups never interact, so the envs of a
+// wave may take different numbers of Newton iterations.
 //
 // Same entry points, argument block and outputs as dmc_kernels.hip; the host
-// only needs `dmc_info[14]` (envs per 64-lane workgroup) to size the grid.
+// only needs `dmc_info` (envs and threads per workgroup, state layout) to size
+// the grid and to present the fields.
 // Reference path replaced: see dmc_kernels.hip (Physics.step, mj_step*, task
 // observation/reward of dm_control.suite).
 

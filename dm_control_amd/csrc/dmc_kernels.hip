@@ -9,13 +9,19 @@
 // native calls of the reference:
 //   Physics.step        /root/reference/dm_control/mujoco/engine.py:149-166
 //   mj_step2 / mj_step / mj_step1 inside libmujoco
-//   task.get_observation / get_reward   suite/{cartpole,cheetah,humanoid}.py
+//   task.get_observation / get_reward   suite/<domain>.py (TASK_* below)
 //
 // Layout: struct-of-arrays state field[k][env] in HBM; one environment per
 // lane, 64-lane workgroups (one wavefront each) so consecutive lanes read
-// consecutive addresses.  Constraint rows live in a per-launch HBM workspace
-// with the same [row*NV + dof][env] layout.  No MFMA: the largest dense object
-// is the NV x NV Hessian (81 entries for cheetah).
+// consecutive addresses.  The per-lane working set lives in registers (the
+// unrolled build indexes everything statically); constraint rows and the
+// contact list are per-lane records in LDS ([word][lane]) with an overflow
+// tier of the same layout in an HBM workspace.  No MFMA: the largest dense
+// object is the NV x NV Hessian (45 packed entries for cheetah).
+//
+// csrc/dmc_coop.hip includes this file for its helpers (math, narrowphase,
+// impedance, touch sensors, task layer, episode initialisation) and supplies
+// the several-lanes-per-env versions of dmc_step / dmc_observe.
 //
 // `real` is float (default) or double (-DDMC_REAL_IS_DOUBLE) -- the fp64 build
 // is the tight-parity mode, the fp32 build is the throughput mode.
