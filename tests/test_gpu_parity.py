@@ -849,3 +849,84 @@ def test_north_star_1000_step_free_run(name):
       assert np.median(e) <= 1e-5, np.median(e)
       assert np.mean(e <= 1e-4) >= 0.85, np.mean(e <= 1e-4)
     hb.free()
+
+
+@pytest.mark.parametrize('name,nsub,steps', [('humanoid', 5, 60), ('walker', 10, 100),
+                                             ('hopper', 4, 150)])
+def test_free_run_trajectories_several_lanes_kernel(name, nsub, steps):
+  """Free-running control steps of the contact-rich 3-D / planar walkers on the
+  several-lanes-per-env kernel against the oracle, identical U(-1,1) action
+  sequences, upright task-like start (standing on / falling onto the floor).
+  fp64: the whole trajectory stays on the oracle's (<= 1e-5 after 300-600
+  physics steps with contact-set changes replayed identically; these systems
+  are chaotic, rounding-order differences of 1e-16 grow by orders of magnitude
+  per hundred steps, so longer horizons separate in any two implementations).
+  fp32: reported only."""
+  nenv = 16
+  model = helpers.load_model(name)
+  rs = np.random.RandomState(2)
+  qpos = np.tile(model.qpos0, (nenv, 1))
+  qvel = 0.01*rs.randn(nenv, model.nv)
+  lim = np.array([bool(model.jnt_limited[j]) and model.jnt_type[j] == 3
+                  for j in range(model.njnt)])
+  adr = np.asarray(model.jnt_qposadr)[lim]
+  lo, hi = np.asarray(model.jnt_range)[lim].T
+  qpos[:, adr] += rs.uniform(0.05*lo, 0.05*hi, (nenv, lim.sum()))
+  ctrls = rs.uniform(-1, 1, (steps, nenv, model.nu))
+  om, datas = _oracle_envs(model, qpos, qvel)
+  contacts = 0
+  for t in range(steps):
+    for i, d in enumerate(datas):
+      d.ctrl[:] = ctrls[t, i]
+      for _ in range(nsub):
+        d.physics_step()
+      contacts += d.ncon > 0
+  assert contacts > steps*nenv//4           # the floor was involved
+  ref = np.array([d.qpos.copy() for d in datas])
+  for precision in ('f64', 'f32'):
+    hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv, 'coop')
+    hb.set_state(qpos.T, qvel.T)
+    for t in range(steps):
+      hb.step_host(ctrls[t], nsub)
+    e = helpers.rel_err(hb.read(W.FIELD_QPOS).T.astype(np.float64), ref)
+    print('%s %s %d-step free run (several lanes per env): median %.2e max %.2e'
+          % (name, precision, steps, np.median(e), e.max()))
+    assert not hb.read(W.FIELD_WARN).any()
+    if precision == 'f64':
+      assert e.max() <= 1e-5, e.max()
+    else:
+      assert np.isfinite(e).all()
+    hb.free()
+
+
+@pytest.mark.parametrize('domain,task,nenv,steps', [('humanoid', 'walk', 2048, 400),
+                                                    ('hopper', 'hop', 4096, 600),
+                                                    ('walker', 'run', 4096, 500)])
+def test_soak_several_lanes_kernel(domain, task, nenv, steps):
+  """Long random-action rollouts on the several-lanes-per-env kernel (bodies
+  pile up on the floor, many simultaneous contacts): no warnings (contact /
+  constraint buffers never overflow, no NaN resets), finite state, rewards in
+  [0, 1], in-kernel returns equal the sum of step rewards."""
+  import torch
+  from dm_control_amd import vec_env
+  env = vec_env.VecEnv(domain, task, nenv, seed=3, torch_io=True)
+  assert env.environment.physics._build_mode == 'coop'    # pylint: disable=protected-access
+  env.reset()
+  gen = torch.Generator(device='cuda').manual_seed(1)
+  nu = env.environment.physics.model.nu
+  acts = [torch.rand(nenv, nu, device='cuda', generator=gen)*2 - 1 for _ in range(16)]
+  total = torch.zeros(nenv, device='cuda')
+  batch = env.environment.physics.batch
+  for t in range(steps):
+    obs, rew, done, _ = env.step(acts[t % 16])
+    total += rew
+    assert not bool(done.any())
+  assert bool(torch.isfinite(obs).all()) and bool(((rew >= 0) & (rew <= 1)).all())
+  assert not batch.read(W.FIELD_WARN).any()
+  stats = batch.read(W.FIELD_STATS)
+  info = batch.model.info
+  assert stats[0].max() <= info.ncon_max and stats[1].max() <= info.nefc_max
+  np.testing.assert_allclose(batch.read(W.FIELD_RETURN), total.cpu().numpy(),
+                             rtol=1e-4, atol=1e-3)
+  print('%s-%s %d envs x %d steps: ncon max %d, nefc max %d, Newton iterations max %d'
+        % (domain, task, nenv, steps, stats[0].max(), stats[1].max(), stats[2].max()))
