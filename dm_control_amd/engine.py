@@ -110,6 +110,55 @@ class _Field:
     return repr(self._get())
 
 
+def _quat_to_mat(q):
+  w, x, y, z = q
+  return np.array([[w*w + x*x - y*y - z*z, 2*(x*y - w*z), 2*(x*z + w*y)],
+                   [2*(x*y + w*z), w*w - x*x + y*y - z*z, 2*(y*z - w*x)],
+                   [2*(x*z - w*y), 2*(y*z + w*x), w*w - x*x - y*y + z*z]])
+
+
+class _Derived:
+  """Read-only `mjData` field computed on the host from the body frames the
+  kernel exports (xpos, xmat): frames of geoms, sites and body inertial frames
+  are fixed offsets in their body (mj_kinematics), so they need no kernel
+  output of their own."""
+
+  def __init__(self, physics, bodyid, pos, quat, want_mat):
+    self._p = physics
+    self._body = np.asarray(bodyid, np.int64).reshape(-1)
+    self._pos = np.asarray(pos, np.float64).reshape(-1, 3)
+    self._rot = np.array([_quat_to_mat(q) for q in
+                          np.asarray(quat, np.float64).reshape(-1, 4)]).reshape(-1, 3, 3)
+    self._want_mat = want_mat
+
+  def _get(self):
+    p = self._p
+    nb = p.model.nbody
+    xpos = np.asarray(p.data.xpos).reshape(-1, nb, 3)
+    xmat = np.asarray(p.data.xmat).reshape(-1, nb, 3, 3)
+    if self._want_mat:
+      out = np.einsum('ebij,bjk->ebik', xmat[:, self._body], self._rot)
+      out = out.reshape(len(xpos), -1)
+    else:
+      out = xpos[:, self._body] + np.einsum('ebij,bj->ebi', xmat[:, self._body],
+                                           self._pos)
+      out = out.reshape(len(xpos), -1)
+    return out[0] if p._squeeze else out
+
+  def _put(self, value):
+    raise ValueError('this field is derived from the body frames and read-only')
+
+  def __array__(self, dtype=None, copy=None):
+    a = self._get()
+    return a if dtype is None else a.astype(dtype)
+
+  def __getitem__(self, idx):
+    return self._get()[idx]
+
+  def __repr__(self):
+    return repr(self._get())
+
+
 class _NamedField:
   """`physics.named.data.<field>[row_name(, col_name)]` (mujoco/index.py)."""
 
@@ -172,6 +221,15 @@ class _Data:
     self.xmat = _Field(p, W.FIELD_XMAT, aux=True)
     self._time = _Field(p, W.FIELD_TIME, None, 'time')
     self._p = p
+    nb = m.nbody
+    ident = np.tile([1.0, 0, 0, 0], (nb, 1))
+    self.xipos = _Derived(p, np.arange(nb), m.body_ipos, ident, False)
+    self.ximat = _Derived(p, np.arange(nb), m.body_ipos, m.body_iquat, True)
+    self.geom_xpos = _Derived(p, m.geom_bodyid, m.geom_pos, m.geom_quat, False)
+    self.geom_xmat = _Derived(p, m.geom_bodyid, m.geom_pos, m.geom_quat, True)
+    if getattr(m, 'nsite', 0):
+      self.site_xpos = _Derived(p, m.site_bodyid, m.site_pos, m.site_quat, False)
+      self.site_xmat = _Derived(p, m.site_bodyid, m.site_pos, m.site_quat, True)
 
   @property
   def time(self):
@@ -230,6 +288,15 @@ class _NamedData:
     self.sensordata = _NamedField(data.sensordata, sens)
     self.xpos = _NamedField(data.xpos, bodies, xyz)
     self.xmat = _NamedField(data.xmat, bodies, mat)
+    self.xipos = _NamedField(data.xipos, bodies, xyz)
+    self.ximat = _NamedField(data.ximat, bodies, mat)
+    geoms = {n: i for i, n in enumerate(m.names.get('geom', [])) if n}
+    self.geom_xpos = _NamedField(data.geom_xpos, geoms, xyz)
+    self.geom_xmat = _NamedField(data.geom_xmat, geoms, mat)
+    if hasattr(data, 'site_xpos'):
+      sites = {n: i for i, n in enumerate(m.names.get('site', [])) if n}
+      self.site_xpos = _NamedField(data.site_xpos, sites, xyz)
+      self.site_xmat = _NamedField(data.site_xmat, sites, mat)
 
 
 class _Named:

@@ -58,15 +58,8 @@ class Physics(engine.Physics):
 
   def to_target(self):
     """Distance from the tip site to the target site."""
-    m = self.model
-    xpos = np.asarray(self.data.xpos).reshape(-1, m.nbody, 3)
-    xmat = np.asarray(self.data.xmat).reshape(-1, m.nbody, 3, 3)
-    def site(name):
-      i = m.name2id(name, 'site')
-      b = m.site_bodyid[i]
-      return xpos[:, b] + np.einsum('eij,j->ei', xmat[:, b], m.site_pos[i])
-    d = np.linalg.norm(site('target') - site('tip'), axis=-1)
-    return d[0] if self.batch_size is None else d
+    site = self.named.data.site_xpos
+    return np.linalg.norm(site['target'] - site['tip'], axis=-1)
 
 
 class Balance(base.Task):

@@ -1,7 +1,5 @@
 """Hopper domain (cf. /root/reference/dm_control/suite/hopper.py)."""
 
-import numpy as np
-
 from dm_control_amd import codegen
 from dm_control_amd import engine
 from dm_control_amd.rl import control
@@ -55,14 +53,8 @@ class Physics(engine.Physics):
 
   def height(self):
     """Height of the torso's centre of mass above the foot's."""
-    m = self.model
-    xpos = np.asarray(self.data.xpos).reshape(-1, m.nbody, 3)
-    xmat = np.asarray(self.data.xmat).reshape(-1, m.nbody, 3, 3)
-    def com_z(name):
-      b = m.name2id(name, 'body')
-      return xpos[:, b, 2] + xmat[:, b, 2].dot(m.body_ipos[b])
-    h = com_z('torso') - com_z('foot')
-    return h[0] if self.batch_size is None else h
+    xipos = self.named.data.xipos
+    return xipos['torso', 'z'] - xipos['foot', 'z']
 
   def speed(self):
     return self.named.data.sensordata['torso_subtreelinvel'][..., 0]

@@ -53,11 +53,8 @@ class Physics(engine.Physics):
   _TASK = codegen.TASK_POINTMASS
 
   def mass_to_target(self):
-    m = self.model
-    xpos = np.asarray(self.data.xpos).reshape(-1, m.nbody, 3)
-    target = m.geom_pos[m.name2id('target', 'geom')]
-    v = target - xpos[:, m.name2id('pointmass', 'body')]
-    return v[0] if self.batch_size is None else v
+    geom = self.named.data.geom_xpos
+    return geom['target'] - geom['pointmass']
 
   def mass_to_target_dist(self):
     return np.linalg.norm(self.mass_to_target(), axis=-1)

@@ -677,6 +677,42 @@ def test_step_sequence_equals_single_steps():
     np.testing.assert_array_equal(a, b)
 
 
+def test_derived_frames_match_oracle():
+  """data.xipos / geom_xpos / geom_xmat / site_xpos are derived on the host from
+  the exported body frames; compared with the oracle's kinematics at the same
+  state, plus the named indexing the suite helpers use."""
+  env = suite.load('acrobot', 'swingup', task_kwargs={'random': 3},
+                   environment_kwargs={'batch_size': 6, 'precision': 'f64'})
+  env.reset()
+  for _ in range(5):
+    env.step(np.zeros((6, 1)))
+  physics = env.physics
+  m = physics.model
+  om = oracle.OracleModel(m)
+  q, v = np.asarray(physics.data.qpos), np.asarray(physics.data.qvel)
+  for i in range(6):
+    d = oracle.OracleData(om)
+    d.qpos[:] = q[i]
+    d.qvel[:] = v[i]
+    d.step1()
+    np.testing.assert_allclose(np.asarray(physics.data.xipos)[i], d.xipos.ravel(), atol=1e-12)
+    np.testing.assert_allclose(np.asarray(physics.data.ximat)[i], d.ximat.ravel(), atol=1e-12)
+    np.testing.assert_allclose(np.asarray(physics.data.geom_xpos)[i], d.geom_xpos.ravel(),
+                               atol=1e-12)
+    np.testing.assert_allclose(np.asarray(physics.data.geom_xmat)[i], d.geom_xmat.ravel(),
+                               atol=1e-12)
+  tip = physics.named.data.site_xpos['tip']
+  lower = np.asarray(physics.data.xpos).reshape(6, -1, 3)[:, 2]
+  zaxis = np.asarray(physics.data.xmat).reshape(6, -1, 3, 3)[:, 2, :, 2]
+  np.testing.assert_allclose(tip, lower + zaxis, atol=1e-12)
+  np.testing.assert_allclose(physics.named.data.site_xpos['target'],
+                             np.tile([0, 0, 4.0], (6, 1)))
+  assert physics.named.data.geom_xpos['lower_arm', 'z'].shape == (6,)
+  with pytest.raises(ValueError):
+    physics.data.geom_xpos._put(0)
+  physics.free()
+
+
 def test_c_abi_argument_errors():
   lib = wrapper.get_lib()
   model = helpers.load_model('cartpole')
