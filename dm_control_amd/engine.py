@@ -299,11 +299,63 @@ class _NamedData:
       self.site_xmat = _NamedField(data.site_xmat, sites, mat)
 
 
+class _NamedArray:
+  """Read-only `named.model.<field>[row(s)(, col)]` view (mujoco/index.py)."""
+
+  def __init__(self, array, rows):
+    self._a = np.asarray(array)
+    self._rows = rows
+
+  def _row(self, key):
+    if isinstance(key, str):
+      if key not in self._rows:
+        raise IndexError('invalid name {!r}'.format(key))
+      return self._rows[key]
+    if isinstance(key, (list, tuple)) and key and isinstance(key[0], str):
+      return [self._row(k) for k in key]
+    return key
+
+  def __getitem__(self, key):
+    if isinstance(key, tuple):
+      return self._a[(self._row(key[0]),) + tuple(key[1:])]
+    return self._a[self._row(key)]
+
+  def __setitem__(self, key, value):
+    raise ValueError(
+        'the compiled model is immutable: what a task varies per episode is '
+        'per-instance task data (DMC_FIELD_TASKDATA), see suite/reacher.py')
+
+  def __array__(self, dtype=None, copy=None):
+    return self._a if dtype is None else self._a.astype(dtype)
+
+  def __repr__(self):
+    return repr(self._a)
+
+
+class _NamedModel:
+  """`physics.named.model`: model arrays indexable by object names."""
+
+  _KINDS = (('body_', 'body'), ('jnt_', 'joint'), ('geom_', 'geom'),
+            ('site_', 'site'), ('actuator_', 'actuator'), ('sensor_', 'sensor'),
+            ('tendon_', 'tendon'))
+
+  def __init__(self, model):
+    self._m = model
+
+  def __getattr__(self, name):
+    value = getattr(self._m, name)
+    for prefix, kind in self._KINDS:
+      if name.startswith(prefix) and isinstance(value, np.ndarray):
+        rows = {n: i for i, n in enumerate(self._m.names.get(kind, [])) if n}
+        return _NamedArray(value, rows)
+    return value
+
+
 class _Named:
 
   def __init__(self, physics, data):
     self.data = _NamedData(physics, data)
-    self.model = physics.model
+    self.model = _NamedModel(physics.model)
 
 
 class Physics(_control.Physics):
