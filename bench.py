@@ -306,6 +306,7 @@ def main():
             'kernel': 'dmc_step',
             'kernel_ms_avg': kernel_ms,
             'algorithmic_bytes_per_launch': bytes_per_launch},
+        'physics_steps_per_s': value*nsub,   # excl. the settle steps of episode resets
         'mean_episode_return': float(returns.mean().item()),
         'envs_with_warnings': int((warn != 0).sum()),
     }
