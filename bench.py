@@ -9,13 +9,23 @@ A "step" is one control step of the whole batch: one launch of the fused kernel
 already resident in HBM, including the episode resets that fall inside the
 timed region (cheetah: 200 settle steps per reset).  Workload at N=1 is the
 configuration BASELINE.json's metric is quoted on: cheetah-run, batch 8192,
-fp32.  N>1 shards independent envs, 8192 per GPU (weak scaling); the only
-collective is an RCCL all-gather of episode returns on the reporting path,
-after the timed region.
+fp32.
+
+N>1 (one process per GPU, `dm_control_amd.distributed`): envs are independent,
+so the env axis is sharded contiguously and NO collective runs in the step.
+  default          weak scaling: --batch envs per GPU (8192)
+  --global-batch G strong scaling: G envs in total, shard_range(G, N, rank) per
+                   GPU (BASELINE configs[3]: --domain humanoid --task walk
+                   --global-batch 8192 = 1024 envs per GPU on 8 GPUs)
+The only collective is the RCCL all-gather of per-env episode returns on the
+reporting path, after the timed region.
 
 Rank 0 prints ONE JSON line with `roofline` (HIP events on the batch's own
 stream) and, at N=1, `cpu_baseline` (the fp64 CPU oracle = "port"; libmujoco
-itself is a closed binary that is not available here).
+itself is a closed binary that is not available here) including the second
+half of BASELINE's metric, qpos rel-err vs the CPU step (teacher-forced per
+step, and free-running at 100 / 1000 steps with the step of the first
+contact-count mismatch).
 """
 
 import argparse
@@ -31,6 +41,9 @@ if _ROOT not in sys.path:
   sys.path.insert(0, _ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md, chip-level parameters
+SIMDS = 1024            # 256 CUs x 4
+VALU_CYCLES = 4         # issue cycles of a wave64 fp32 VALU instruction
+CLOCK_GHZ = 2.4
 
 
 def algorithmic_bytes_per_env_step(info, real_size):
@@ -40,19 +53,21 @@ def algorithmic_bytes_per_env_step(info, real_size):
   return (reads + writes)*real_size
 
 
-def measured_traffic(domain, task, batch, precision):
-  """HBM bytes per launch from the committed PMC summary of this workload.
+def counters_for(code_object, batch):
+  """PMC figures of THIS code object at THIS batch size, or None.
 
   rocprofv3 counters cannot be collected from inside the timed run; they come
-  from separate `--pmc` passes of this same script (profiles/README.md) and
-  are only reported for the exact workload they were measured on.
+  from separate `--pmc` passes of this same script (profiles/README.md,
+  tools/collect_counters.py).  Each summary records the code object it was
+  measured on (the content hash in the .hsaco file name: model, precision,
+  kernel sources and flags), so a changed kernel never inherits old numbers.
   """
-  path = os.path.join(_ROOT, 'profiles', 'r01_pmc_%s_%s_b%d_%s.json'
-                      % (domain, task, batch, precision))
+  tag = os.path.basename(code_object).replace('dmc_', '').replace('.hsaco', '')
+  path = os.path.join(_ROOT, 'profiles', 'counters_%s_b%d.json' % (tag, batch))
   try:
     with open(path) as f:
-      return json.load(f)['traffic_bytes_per_launch']
-  except (OSError, ValueError, KeyError):
+      return json.load(f)
+  except (OSError, ValueError):
     return None
 
 
@@ -73,13 +88,12 @@ def usable_cores():
   return n
 
 
-def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None):
+def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None,
+                 free_run_steps=1000):
   """Times the fp64 oracle (OpenMP over envs) on a bounded sample.
 
   With `gpu_batch` (the benchmarked batch) the same leg also reports the
-  second half of BASELINE's metric, "qpos rel-err vs CPU mj_step": 64 states
-  taken from the benchmarked batch are stepped by the benchmarked code object
-  and by the oracle, teacher-forced, under the same controls.
+  second half of BASELINE's metric, "qpos rel-err vs CPU mj_step".
   """
   from dm_control_amd import suite as _suite  # host logic only (model compile)
   from dm_control_amd.mjcf import compiler
@@ -126,21 +140,44 @@ def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None):
                 'fp64 C restatement of mj_step, OpenMP over envs, %.1f s'
                 % (domain, task, nenv, reps, nsub, dt)}
   if gpu_batch is not None:
-    out['qpos_rel_err'] = _rel_err_sample(gpu_batch, om, oracle, nsub)
+    out['qpos_rel_err'] = {
+        'definition': 'max|q_gpu - q_cpu| / max(1, max|q_cpu|) per env; CPU = '
+                      'fp64 oracle (KAT-pinned restatement, not libmujoco)',
+        'teacher_forced': _rel_err_sample(gpu_batch, om, oracle, nsub),
+        'free_run': _free_run_sample(gpu_batch, om, oracle, nsub, cores,
+                                     steps=free_run_steps)}
   return out
 
 
-def _rel_err_sample(gpu_batch, om, oracle, nsub, nenv=64, steps=20):
-  """max|q_gpu - q_cpu| / max(1, max|q_cpu|) per env and control step."""
-  from dm_control_amd import wrapper
-  W = wrapper
-  model = om.model
+def _start_states(gpu_batch, nenv):
+  from dm_control_amd import wrapper as W
   q0 = gpu_batch.read(W.FIELD_QPOS).T[:nenv].astype(np.float64)
   v0 = gpu_batch.read(W.FIELD_QVEL).T[:nenv].astype(np.float64)
-  nenv = len(q0)
-  hb = W.HipBatch(gpu_batch.model, nenv)       # same code object as the bench
-  if model.nu and gpu_batch.model.info.ntaskdata:
+  w0 = gpu_batch.read(W.FIELD_WARMSTART).T[:nenv].astype(np.float64)
+  return q0, v0, w0
+
+
+def _twin_batch(gpu_batch, nenv):
+  """A small batch on the same code object as the bench, same task data."""
+  from dm_control_amd import wrapper as W
+  hb = W.HipBatch(gpu_batch.model, nenv)
+  if gpu_batch.model.info.ntaskdata:
     hb.write(W.FIELD_TASKDATA, gpu_batch.read(W.FIELD_TASKDATA)[:, :nenv])
+  return hb
+
+
+def _rel(q, ref):
+  return np.abs(q - ref).max(axis=1)/np.maximum(1, np.abs(ref).max(axis=1))
+
+
+def _rel_err_sample(gpu_batch, om, oracle, nsub, nenv=64, steps=20):
+  """Teacher-forced: both sides restart every control step from the oracle's
+  state (incl. its warm start) under the same controls."""
+  from dm_control_amd import wrapper as W
+  model = om.model
+  q0, v0, _ = _start_states(gpu_batch, nenv)
+  nenv = len(q0)
+  hb = _twin_batch(gpu_batch, nenv)
   datas = [oracle.OracleData(om) for _ in range(nenv)]
   for i, d in enumerate(datas):
     d.qpos[:] = q0[i]
@@ -161,14 +198,63 @@ def _rel_err_sample(gpu_batch, om, oracle, nsub, nenv=64, steps=20):
       for _ in range(nsub):
         d.physics_step()
     nq = np.array([d.qpos.copy() for d in datas])
-    errs.append(np.abs(q - nq).max(axis=1)/np.maximum(1, np.abs(nq).max(axis=1)))
+    errs.append(_rel(q, nq))
   hb.free()
   e = np.concatenate(errs)
   return {'median': float(np.median(e)), 'p99': float(np.percentile(e, 99)),
           'max': float(e.max()),
-          'sample': 'teacher-forced, %d envs from the benchmarked batch x %d '
-                    'control steps, same code object, U(-1,1) controls'
-                    % (nenv, steps)}
+          'sample': '%d envs from the benchmarked batch x %d control steps, same '
+                    'code object, U(-1,1) controls' % (nenv, steps)}
+
+
+def _free_run_sample(gpu_batch, om, oracle, nsub, cores, nenv=64, steps=1000):
+  """Free-running: both sides start from the same states of the benchmarked
+  batch and see the same U(-1,1) controls for `steps` control steps; no state
+  is ever copied across.  Reports the error at 100 and `steps` steps, the share
+  of envs within BASELINE's 1e-4, and the control step at which an env's contact
+  count first differs from the oracle's (from there on the two are different
+  trajectories of a chaotic system, in any pair of implementations)."""
+  from dm_control_amd import wrapper as W
+  model = om.model
+  q0, v0, w0 = _start_states(gpu_batch, nenv)
+  nenv = len(q0)
+  hb = _twin_batch(gpu_batch, nenv)
+  hb.set_state(q0.T, v0.T, w0.T)
+  datas = [oracle.OracleData(om) for _ in range(nenv)]
+  for i, d in enumerate(datas):
+    d.qpos[:] = q0[i]
+    d.qvel[:] = v0[i]
+    d.qacc_warmstart[:] = w0[i]
+    d.step1()
+  rs = np.random.RandomState(2)
+  first = np.full(nenv, steps + 1)
+  marks = {}
+  for t in range(steps):
+    ctrl = rs.uniform(-1, 1, (nenv, model.nu))
+    hb.step_host(ctrl, nsub)
+    # contacts the LAST physics step of this control step acted on
+    if nsub > 1:
+      oracle.batch_step(om, datas, ctrl, nsub - 1, cores)
+    ref = np.array([d.ncon for d in datas])
+    oracle.batch_step(om, datas, ctrl, 1, cores)
+    ncon = hb.read(W.FIELD_STATS)[0]
+    new = (ncon != ref) & (first > steps)
+    first[new] = t + 1
+    if t + 1 in (100, steps):
+      q = hb.read(W.FIELD_QPOS).T.astype(np.float64)
+      e = _rel(q, np.array([d.qpos.copy() for d in datas]))
+      marks['step_%d' % (t + 1)] = {
+          'median': float(np.median(e)), 'p90': float(np.percentile(e, 90)),
+          'max': float(e.max()), 'frac_within_1e-4': float(np.mean(e <= 1e-4))}
+  hb.free()
+  out = dict(marks)
+  mism = first <= steps
+  out['first_contact_count_mismatch'] = {
+      'envs': int(mism.sum()),
+      'earliest_step': int(first.min()) if mism.any() else None}
+  out['sample'] = ('%d envs from the benchmarked batch, %d free-running control '
+                   'steps, same code object, U(-1,1) controls' % (nenv, steps))
+  return out
 
 
 def main():
@@ -178,30 +264,41 @@ def main():
   ap.add_argument('--warmup', type=int, default=50)
   ap.add_argument('--domain', default='cheetah')
   ap.add_argument('--task', default='run')
-  ap.add_argument('--batch', type=int, default=8192, help='envs per GPU')
+  ap.add_argument('--batch', type=int, default=8192,
+                  help='envs per GPU (weak scaling)')
+  ap.add_argument('--global-batch', type=int, default=None,
+                  help='total envs, sharded over the GPUs (strong scaling)')
   ap.add_argument('--precision', default='f32', choices=['f32', 'f64'])
   ap.add_argument('--no-cpu-baseline', action='store_true')
   args = ap.parse_args()
 
   import torch
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch with torch.distributed.run for --gpus > 1')
+  from dm_control_amd import distributed
+  world_env = int(os.environ.get('WORLD_SIZE', '1'))
+  if world_env != args.gpus and world_env == 1 and args.gpus > 1:
+    raise SystemExit('launch with torch.distributed.run for --gpus > 1')
   # under torchrun (RANK set) the RCCL path is taken even for one rank, so the
   # process-group / all-gather code is exercised on a single-GPU box as well
-  distributed = world > 1 or 'RANK' in os.environ
-  if distributed:
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  rank, world = distributed.init_process_group(
+      'nccl', single_rank_group='RANK' in os.environ)
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  import torch.distributed as dist
+  in_group = dist.is_available() and dist.is_initialized()
+
+  if args.global_batch is not None:
+    start, stop = distributed.shard_range(args.global_batch, world, rank)
+    scaling, total_envs = 'strong', args.global_batch
+  else:
+    start, stop = rank*args.batch, (rank + 1)*args.batch
+    scaling, total_envs = 'weak', args.batch*world
+  nlocal = stop - start
+  seeds = distributed.env_seeds(1000, total_envs, world, rank) \
+      if args.global_batch is not None else np.arange(start, stop) + 1000
 
   from dm_control_amd import suite, wrapper
-  env = suite.load(args.domain, args.task, task_kwargs={'random': 1000 + rank},
-                   environment_kwargs={'batch_size': args.batch,
+  env = suite.load(args.domain, args.task,
+                   task_kwargs={'random': int(seeds[0])},
+                   environment_kwargs={'batch_size': nlocal,
                                        'device': local_rank,
                                        'precision': args.precision,
                                        'device_init': True})
@@ -213,18 +310,20 @@ def main():
   tdtype = torch.float32 if args.precision == 'f32' else torch.float64
   dev = torch.device('cuda', local_rank)
   gen = torch.Generator(device=dev)
-  gen.manual_seed(rank)
+  gen.manual_seed(int(seeds[0]))
   # 16 steps of actions U(-1,1), resident in HBM, [t][env][nu]
-  pool = torch.rand(16, args.batch, info.nu, device=dev, dtype=tdtype,
+  pool = torch.rand(16, nlocal, info.nu, device=dev, dtype=tdtype,
                     generator=gen)*2 - 1
   torch.cuda.synchronize(dev)
 
-  state = {'count': 0, 'ev_ms': 0.0, 'ev_launches': 0, 'timing': False}
+  state = {'count': 0, 'ev_ms': 0.0, 'ev_launches': 0, 'timing': False,
+           'resets': 0}
 
-  def reset_episode():
+  def reset_episode(timed=False):
     with physics.reset_context():
       task.initialize_episode(physics)
     state['count'] = 0
+    state['resets'] += int(timed)
 
   def run(nsteps, timed):
     # One launch per control step; the launches of up to 16 steps are issued by
@@ -237,12 +336,12 @@ def main():
           ms, n = batch.timer_stop()
           state['ev_ms'] += ms; state['ev_launches'] += n
           state['timing'] = False
-        reset_episode()
+        reset_episode(timed)
       if timed and not state['timing']:
         batch.timer_start()
         state['timing'] = True
       chunk = int(min(16, nsteps - done, step_limit - state['count']))
-      batch.step_device_n(pool.data_ptr(), 1, info.nu, args.batch*info.nu,
+      batch.step_device_n(pool.data_ptr(), 1, info.nu, nlocal*info.nu,
                           chunk, nsub)
       state['count'] += chunk
       done += chunk
@@ -255,14 +354,14 @@ def main():
   run(args.warmup, False)
   batch.sync()
   torch.cuda.synchronize(dev)
-  if distributed:
+  if in_group:
     dist.barrier()
   t0 = time.perf_counter()
   run(args.steps, True)
   batch.sync()
   torch.cuda.synchronize(dev)
   elapsed = time.perf_counter() - t0
-  if distributed:
+  if in_group:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -271,38 +370,56 @@ def main():
   # reporting path: all-gather of per-env episode returns over RCCL/xGMI
   returns = torch.from_numpy(
       batch.read(wrapper.FIELD_RETURN).astype(np.float32)).to(dev)
-  if distributed:
-    gathered = [torch.empty_like(returns) for _ in range(world)]
-    dist.all_gather(gathered, returns)
-    returns = torch.cat(gathered)
+  returns = distributed.gather_episode_returns(returns, total_envs)
   warn = batch.read(wrapper.FIELD_WARN)
 
   if rank == 0:
-    total_envs = args.batch*world
     value = total_envs*args.steps/elapsed
     kernel_ms = state['ev_ms']/max(1, state['ev_launches'])
     bytes_per_launch = algorithmic_bytes_per_env_step(
-        info, info.real_size)*args.batch
+        info, info.real_size)*nlocal
     achieved = bytes_per_launch/(kernel_ms*1e-3)/1e9 if kernel_ms > 0 else 0.0
+    code_object = physics.code_object
+    counters = counters_for(code_object, nlocal) or {}
+    valu = None
+    if counters.get('valu_insts_per_launch') and kernel_ms > 0:
+      insts = counters['valu_insts_per_launch']
+      valu = {
+          'insts_per_wave': insts/max(1, counters.get('waves_per_launch', 1)),
+          'valu_busy_on_occupied_simd': counters.get('valu_busy'),
+          'chip_issue_frac': insts*VALU_CYCLES/(
+              SIMDS*kernel_ms*1e-3*CLOCK_GHZ*1e9),
+          'source': counters.get('source')}
+    resets = ', %d episode reset(s) inside the timed region' % state['resets'] \
+        if state['resets'] else ''
     line = {
         'metric': 'env-steps/sec', 'value': value, 'unit': 'env-steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed/args.steps*1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None,
+        'scaling': scaling, 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
         'config': {
-            'workload': '%s-%s batch=%d per GPU (dm_control.suite, %d physics '
-                        'substeps per env-step, episode resets included)'
-                        % (args.domain, args.task, args.batch, nsub),
-            'global_batch': total_envs, 'parallelism': 'env-shard x%d' % world,
-            'actions': 'U(-1,1), device-resident'},
+            'workload': '%s-%s, %d envs per GPU (dm_control.suite, %d physics '
+                        'substeps per env-step%s)'
+                        % (args.domain, args.task, nlocal, nsub, resets),
+            'global_batch': total_envs,
+            'parallelism': 'env-shard x%d (%s: %s)' % (
+                world, scaling,
+                '%d envs in total' % total_envs if scaling == 'strong'
+                else '%d envs per GPU' % args.batch),
+            'actions': 'U(-1,1), device-resident',
+            'code_object': os.path.basename(code_object),
+            'kernel_shape': physics.kernel_shape},
         'roofline': {
-            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            # the contract's figure (north_star: achieved HBM GB/s vs 8 TB/s);
+            # what actually limits the kernel is VALU issue, see `valu`
+            'bound': 'hbm', 'limited_by': 'valu-issue',
+            'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS,
-            'traffic': measured_traffic(args.domain, args.task, args.batch,
-                                        args.precision),
+            'traffic': counters.get('traffic_bytes_per_launch'),
             'traffic_unit': 'bytes/launch (rocprofv3 FETCH_SIZE+WRITE_SIZE, '
-                            'separate passes, see profiles/)',
+                            'separate passes on this code object, see profiles/)',
+            'valu': valu,
             'kernel': 'dmc_step',
             'kernel_ms_avg': kernel_ms,
             'algorithmic_bytes_per_launch': bytes_per_launch},
@@ -314,7 +431,7 @@ def main():
       line['cpu_baseline'] = cpu_baseline(args.domain, args.task, nsub,
                                           gpu_batch=batch)
     print(json.dumps(line))
-  if distributed:
+  if in_group:
     dist.destroy_process_group()
 
 

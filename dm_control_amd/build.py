@@ -71,8 +71,10 @@ def model_key(model, task, precision, ncon_max=None, extra_flags=(),
 
 
 def _spills(remarks, kernel='dmc_step'):
-  """(vgpr, sgpr) spill counts of `kernel` from -Rpass-analysis remarks."""
-  vg = sg = 0
+  """(vgpr, sgpr) spill counts of `kernel` from -Rpass-analysis remarks, or
+  None if the remarks do not hold them (the caller then treats the build as
+  over budget: the guard fails closed)."""
+  vg = sg = None
   inside = False
   for line in remarks.splitlines():
     if 'Function Name:' in line:
@@ -81,7 +83,14 @@ def _spills(remarks, kernel='dmc_step'):
       vg = int(line.split('VGPRs Spill:')[1].split()[0])
     elif inside and 'SGPRs Spill:' in line:
       sg = int(line.split('SGPRs Spill:')[1].split()[0])
+  if vg is None or sg is None:
+    return None
   return vg, sg
+
+
+def _within_spill_budget(spills):
+  return (spills is not None and spills[0] <= MAX_VGPR_SPILLS
+          and spills[1] <= MAX_SGPR_SPILLS)
 
 
 def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
@@ -149,7 +158,7 @@ def lds_budget_for(nenv):
 
 def build_model(model, task=codegen.TASK_NONE, precision='f32',
                 ncon_max=None, force=False, keep_temps=False, extra_flags=None,
-                mode='auto', lds_budget=None, group=64, lanes=64):
+                mode='auto', lds_budget=None, group=64):
   """Generates the constants header for `model` and compiles its kernels.
 
   mode: "unrolled" (static indexing, per-lane state in registers), "rolled"
@@ -168,10 +177,6 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
   if lds_budget is not None and lds_budget != 128*1024:
     extra_flags = tuple(extra_flags) + ('-DDMC_LDS_BUDGET=%d' % lds_budget,)
-  if lanes not in (16, 32, 64):
-    raise ValueError('lanes (envs per workgroup) must be 16, 32 or 64')
-  if lanes != 64 and mode != 'coop':
-    extra_flags = tuple(extra_flags) + ('-DDMC_LANES=%d' % lanes,)
   os.makedirs(_BUILD, exist_ok=True)
   if mode == 'coop':
     # several lanes per env (csrc/dmc_coop.hip): working set in LDS, generic
@@ -192,22 +197,28 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     return os.path.join(_BUILD, 'dmc_%s.hsaco' % model_key(
         model, task, precision, ncon_max, extra_flags, unroll))
   marker = path(True) + '.rolled'     # "auto" decided against the unrolled build
+  vetted = path(True) + '.ok'         # spill counts recorded and within budget
   if not force:
-    if mode != 'rolled' and os.path.exists(path(True)):
+    if mode != 'rolled' and os.path.exists(path(True)) and (
+        mode == 'unrolled' or os.path.exists(vetted)):
       return path(True)
     if mode != 'unrolled' and os.path.exists(path(False)) and (
         mode == 'rolled' or os.path.exists(marker)):
       return path(False)
   if mode != 'rolled':
     out = path(True)
-    vg, sg = _compile(model, task, precision, ncon_max, extra_flags, True, out,
+    spills = _compile(model, task, precision, ncon_max, extra_flags, True, out,
                       keep_temps)
-    if mode == 'unrolled' or (vg <= MAX_VGPR_SPILLS and sg <= MAX_SGPR_SPILLS):
+    ok = _within_spill_budget(spills)
+    if mode == 'unrolled' or ok:
       os.replace(out + '.tmp', out)
+      if ok:
+        with open(vetted, 'w') as f:
+          f.write('vgpr spills %d, sgpr spills %d\n' % spills)
       return out
     os.remove(out + '.tmp')
     with open(marker, 'w') as f:
-      f.write('vgpr spills %d, sgpr spills %d\n' % (vg, sg))
+      f.write('spills (vgpr, sgpr): %r\n' % (spills,))
   out = path(False)
   _compile(model, task, precision, ncon_max, extra_flags, False, out,
            keep_temps)

@@ -251,8 +251,13 @@ int dmc_batch_create(const dmc_model* model, int nenv, dmc_batch** out) {
     err = hipMalloc(&b->field[f], b->bytes[f]);
     if (err == hipSuccess) err = hipMemset(b->field[f], 0, b->bytes[f]);
   }
+  // workspace: ws_per_env reals per env, laid out for the batch rounded up to
+  // whole 64-env workgroups (surplus lanes of the last workgroup own a slot)
+  const size_t npad = (n + 63)/64*64;
   if (err == hipSuccess)
-    err = hipMalloc(&b->ws, atleast1(i.ws_per_env)*n*rs);
+    err = hipMalloc(&b->ws, atleast1(i.ws_per_env)*npad*rs);
+  if (err == hipSuccess)
+    err = hipMemset(b->ws, 0, atleast1(i.ws_per_env)*npad*rs);
   if (err == hipSuccess) err = hipEventCreate(&b->ev0);
   if (err == hipSuccess) err = hipEventCreate(&b->ev1);
   if (err != hipSuccess) {
@@ -392,7 +397,8 @@ int dmc_batch_step(dmc_batch* b, const void* ctrl, long long stride_k,
   DmcArgs a;
   fill_args(b, a);
   a.nsub = nsub;
-  a.flags = want_outputs ? 0 : DMC_FLAG_NO_OUTPUT;
+  a.flags = (want_outputs & DMC_STEP_OUTPUTS) ? 0 : DMC_FLAG_NO_OUTPUT;
+  if (want_outputs & DMC_STEP_STALE_FIRST) a.flags |= DMC_FLAG_STALE_FIRST;
   if (ctrl && i.nu > 0) {
     a.flags |= DMC_FLAG_CTRL;
     if (on_device) {

@@ -38,3 +38,4 @@ struct DmcArgs {
 #define DMC_FLAG_ONLY_COLLIDING 8
 #define DMC_FLAG_RESET_ONLY 16     // dmc_init_episode: mj_resetData only
 #define DMC_FLAG_TASKDATA_DEFAULT 32  // dmc_init_episode: task data <- model values
+#define DMC_FLAG_STALE_FIRST 64    // dmc_step: first substep takes its acceleration from the reset state

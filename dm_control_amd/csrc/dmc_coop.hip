@@ -1298,12 +1298,36 @@ struct Coop {
     return gany(ba);
   }
 
-  // one `Physics.step()`
-  __device__ void physics_step(real tol) {
+  // one `Physics.step()`; `stale`: acceleration from the position/velocity
+  // stage of the reset state, applied to the current state (the first of the
+  // cheetah's settle steps, see physics_step in dmc_kernels.hip)
+  __device__ void physics_step(real tol, bool stale = false) {
     const real h = R(timestep);
     check_state();
     if (!RK4) {
+      constexpr int KQ = (NQX + G - 1)/G, KV = (NVX + G - 1)/G;
+      real qkeep[KQ], vkeep[KV];
+      if (stale) {
+        _Pragma("unroll")
+        for (int t = 0; t < KQ; t++) {
+          const int i = l + t*G;
+          if (i < NQ) { qkeep[t] = S[off::QPOS + i]; S[off::QPOS + i] = R(qpos0[i]); }
+        }
+        _Pragma("unroll")
+        for (int t = 0; t < KV; t++) {
+          const int i = l + t*G;
+          if (i < NV) { vkeep[t] = S[off::QVEL + i]; S[off::QVEL + i] = 0; }
+        }
+        gsync();
+      }
       forward(true, tol);
+      if (stale) {
+        _Pragma("unroll")
+        for (int t = 0; t < KQ; t++) if (l + t*G < NQ) S[off::QPOS + l + t*G] = qkeep[t];
+        _Pragma("unroll")
+        for (int t = 0; t < KV; t++) if (l + t*G < NV) S[off::QVEL + l + t*G] = vkeep[t];
+        gsync();
+      }
       if (bad_qacc()) { warn |= WARN_BADQACC; reset_state(); return; }
       bool damped = false;
       for (int i = 0; i < NV; i++) damped |= dof_damping[i] > 0;
@@ -1471,7 +1495,8 @@ dmc_step(DmcArgs a) {
   for (int k = 0; k < PH_N; k++) C.tprof[k] = 0;
   C.tlast = wall_clock64();
 #endif
-  for (int s = 0; s < a.nsub; s++) C.physics_step(tol);
+  for (int s = 0; s < a.nsub; s++)
+    C.physics_step(tol, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
 #ifdef DMC_COOP_PROFILE
   { const long long t_ = wall_clock64(); C.tprof[PH_EULER] += t_ - C.tlast; C.tlast = t_; }
 #endif

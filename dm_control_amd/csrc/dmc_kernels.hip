@@ -38,9 +38,15 @@ typedef double real;   // must match dmc_real in the generated header
 #define DMC_F32_RULES 0
 #else
 typedef float real;
+#define DMC_MINVAL 1e-15f
+#ifdef DMC_F64_RULES
+// experiment (tools/gpu_precision_study.py): fp32 arithmetic with the fp64
+// build's unmodified stopping rules, to separate rounding from the rules below
+#define DMC_TOL_FLOOR 0.0
+#define DMC_F32_RULES 0
+#else
 // fp32 cannot resolve cost changes below ~1e-7 relative; see DESIGN.md
 #define DMC_TOL_FLOOR 1e-6
-#define DMC_MINVAL 1e-15f
 // fp32-only stopping rules: the absolute 1e-8-style thresholds of
 // the fp64 algorithm sit below fp32 rounding noise of the cost, so the solver
 // additionally stops (a) the line search once the directional derivative has
@@ -48,6 +54,7 @@ typedef float real;
 // after a full step (alpha ~ 1) that left the active set unchanged -- at that
 // point the iterate is the exact minimiser of the current quadratic piece.
 #define DMC_F32_RULES 1
+#endif
 #endif
 
 #ifndef DMC_MODEL_HEADER
@@ -57,29 +64,6 @@ typedef float real;
 
 using namespace dmc_model;
 
-// unroll factor of the loops over LDS-resident constraint rows: with one wave
-// per SIMD the only way to overlap a row's LDS round trip is the next row's
-#ifndef DMC_ROW_UNROLL
-#define DMC_ROW_UNROLL 1
-#endif
-#define DMC_STR_(x) #x
-#define DMC_STR(x) DMC_STR_(x)
-#if DMC_ROW_UNROLL > 1
-#define DMC_ROW_UNROLL_PRAGMA _Pragma(DMC_STR(unroll DMC_ROW_UNROLL))
-#else
-#define DMC_ROW_UNROLL_PRAGMA
-#endif
-// Optional scheduling fence (-DDMC_SCHED_FENCE_ON): forces the LDS loads of a
-// constraint row to be issued before their uses.  Measured: no gain on cheetah
-// (0.0698 vs 0.0688 ms -- the row loops are VALU-bound at the per-wave maximum
-// row count, not latency-bound) and a loss on cart-pole (0.019 -> 0.031 ms), so
-// it is off; the row lambdas still load their words first, which is what lets
-// the scheduler batch them when it has the registers.
-#if defined(DMC_SCHED_FENCE_ON) && !defined(DMC_HOST_SHIM)
-#define DMC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define DMC_SCHED_FENCE() do {} while (0)
-#endif
 // line-search evaluations per Newton iteration (experiments may lower it)
 #ifndef DMC_LS_MAXIT
 #define DMC_LS_MAXIT (DMC_F32_RULES ? 20 : 50)
@@ -90,29 +74,8 @@ using namespace dmc_model;
 #define DEVN static __device__ __forceinline__
 
 constexpr int NM = NV*(NV + 1)/2;      // packed lower triangle
-// Envs (= active lanes) per workgroup.  A wave costs what its busiest lane costs
-// (rows x Newton iterations), so while the batch leaves SIMDs idle anyway
-// (8192 envs = 128 full waves on 1024 SIMDs) thinner workgroups -- 32 or 16
-// envs in a 64-wide wave -- shorten the launch: the maximum over 16 envs is
-// smaller than over 64.  The LDS record stride follows, so four 16-env
-// workgroups need the LDS of one 64-env workgroup.
-#ifndef DMC_LANES
-#define DMC_LANES 64
-#endif
-constexpr int LANES = DMC_LANES;
-static_assert(LANES == 16 || LANES == 32 || LANES == 64, "envs per workgroup");
-// Optional "big matrix" storage (-DDMC_BIGMAT=1): M in the HBM workspace, its
-// factor / the Newton Hessian in one LDS-resident (fp32) or HBM-resident (fp64)
-// buffer instead of per-lane registers.  Measured on the 27-dof humanoid it is
-// SLOWER with one env per lane (55.8 vs 11.9 ms per launch: the unrolled code's
-// live ranges still overflow the register file, spills rise from 2232 to 3318),
-// so it is off by default; it is the storage layout the several-lanes-per-env
-// solver will use and is kept compiling under the host sanitizers.
-#ifndef DMC_BIGMAT
-#define DMC_BIGMAT 0
-#endif
-constexpr bool BIGMAT = DMC_BIGMAT != 0 && NM > 0;
-constexpr int MAT_REGS = BIGMAT ? 1 : (NM > 0 ? NM : 1);
+constexpr int LANES = 64;               // envs per workgroup = one wavefront
+constexpr int MAT_REGS = NM > 0 ? NM : 1;
 constexpr int NVX = NV > 0 ? NV : 1;
 constexpr int NUX = NU > 0 ? NU : 1;
 constexpr int NQX = NQ > 0 ? NQ : 1;
@@ -262,24 +225,11 @@ DEV real dot6(const real* a, const real* b) {
 }
 DEV int tri(int i, int j) { return i*(i + 1)/2 + j; }   // i >= j
 
-// Packed symmetric nv x nv matrices behind one accessor interface:
-//   RegMat  per-lane register array (small models: everything static)
-//   LdsMat  [entry][lane] in LDS     (nv ~ 27: 378 entries do not fit in VGPRs
-//   GlbMat  [entry][env] in HBM       next to the rest of the working set)
+// packed symmetric nv x nv matrix in a per-lane register array
 struct RegMat {
   real* v;
   __device__ __forceinline__ real get(int i) const { return v[i]; }
   __device__ __forceinline__ void set(int i, real x) const { v[i] = x; }
-};
-struct LdsMat {
-  real* p;
-  __device__ __forceinline__ real get(int i) const { return p[i*LANES]; }
-  __device__ __forceinline__ void set(int i, real x) const { p[i*LANES] = x; }
-};
-struct GlbMat {
-  real* p; long long n;
-  __device__ __forceinline__ real get(int i) const { return p[i*n]; }
-  __device__ __forceinline__ void set(int i, real x) const { p[i*n] = x; }
 };
 
 // y = A x for packed symmetric A
@@ -322,12 +272,7 @@ DEV int chol_factor_t(const Mat& A) {
   }
   return nbad;
 }
-// shared out-of-line copies for the memory-resident forms (three call sites)
-static __device__ __noinline__ int chol_factor_lds(real* p) { return chol_factor_t(LdsMat{p}); }
-static __device__ __noinline__ int chol_factor_glb(real* p, long long n) { return chol_factor_t(GlbMat{p, n}); }
 DEV int chol_factor(const RegMat& A) { return chol_factor_t(A); }
-DEV int chol_factor(const LdsMat& A) { return chol_factor_lds(A.p); }
-DEV int chol_factor(const GlbMat& A) { return chol_factor_glb(A.p, A.n); }
 
 template <class Mat>
 DEV void chol_solve(real* x, const Mat& L) {
@@ -352,13 +297,16 @@ DEV void chol_solve(real* x, const Mat& L) {
 // ---------------------------------------------------------------------------
 struct Env {
   real qpos[NQ > 0 ? NQ : 1], qvel[NVX], ctrl[NUX], warm[NVX];
+#ifdef DMC_STATE_COMP
+  real qpos_lo[NQ > 0 ? NQ : 1], qvel_lo[NVX];   // low words of the fp64 state
+#endif
   real xpos[NBODY*3], xquat[NBODY*4], xmat[NBODY*9];
   real xipos[NBODY*3], ximat[NBODY*9];
   real xanchor[(NJNT > 0 ? NJNT : 1)*3], xaxis[(NJNT > 0 ? NJNT : 1)*3];
   real subtree_com[NBODY*3];
   real cinert[NBODY*10];
   real cdof[NVX*6], cdof_dot[NVX*6], cvel[NBODY*6];
-  real qM[MAT_REGS], qL[MAT_REGS];   // register-resident only in small mode
+  real qM[MAT_REGS], qL[MAT_REGS];
   real qfrc_smooth[NVX], qfrc_constraint[NVX], qacc_smooth[NVX], qacc[NVX];
   real subtree_linvel[NBODY*3];
   real touch[NTOUCH > 0 ? NTOUCH : 1];   // touch sensor readings (mj_sensorAcc)
@@ -370,35 +318,51 @@ struct Env {
   unsigned warn;
 };
 
-// Constraint rows: record r = [J(0..NV-1), D, aref, Jaref, Jv].  The first
-// LDS_ROWS records of each lane live in LDS ([record word][lane]: every lane
-// hits its own bank, conflict-free for any per-lane row index); records beyond
-// that spill to the HBM workspace with the same [word][env] layout.
-// Contact records ([pos3 n3 tangent-hint3 dist pair]) use the same two tiers.
-constexpr int RW = NV + 4;
+// Constraint rows: record = [J(0..NV-1), D, aref, Jaref, Jv (, owner env)].
+// Records are stored in "rounds" of LANES slots, [round][word][slot]; the first
+// LDS_ROWS rounds live in LDS, the rest in the HBM workspace of the workgroup.
+//
+// Row-parallel solver (ROWPAR, the default whenever its per-env exchange buffer
+// fits): the rows of the whole workgroup are packed densely -- env e owns the
+// slots base[e] .. base[e] + nefc[e] - 1, base = exclusive prefix sum of the
+// row counts -- so that in the solver passes lane l of round k handles slot
+// 64 k + l whatever env it belongs to: a pass costs (total rows)/64 rounds
+// instead of max_e nefc[e] rounds, and slot addresses are lane-contiguous
+// (conflict-free LDS access).  Per-env sums (Hessian, forces, line-search
+// terms) are reduced with LDS float atomics into the exchange buffer.
+// Otherwise (very large NV) env e keeps its row r in slot e of round r and every
+// lane walks its own rows (the round count is then the per-env row count).
+// Contact records ([pos3 n3 tangent-hint3 dist pair]) are per-lane in both
+// modes: record k of every lane in one [word][lane] block.
 constexpr int CW = 11;
 #ifndef DMC_LDS_BUDGET
-#define DMC_LDS_BUDGET (BIGMAT ? 156*1024 : 128*1024)
+#define DMC_LDS_BUDGET (128*1024)
 #endif
 #ifndef DMC_CON_LDS
 #define DMC_CON_LDS 12
 #endif
-constexpr int REC_BYTES = LANES*(int)sizeof(real);    // one record word, all lanes
-// big-matrix mode: the factor/Hessian buffer gets LDS first if it leaves room
-constexpr bool MAT_IN_LDS = BIGMAT && NM*REC_BYTES + 4*(RW + CW)*REC_BYTES <= DMC_LDS_BUDGET;
-// Small mode with the mass matrix in LDS (-DDMC_M_LDS=1): M is live from the
-// CRBA to the integrator, i.e. across the whole Newton solver, where its NM
-// registers are the difference between a scheduler that can batch the LDS loads
-// of a constraint row and one that must wait for every pair of words.
-#ifndef DMC_M_LDS
-#define DMC_M_LDS 0
+#ifndef DMC_ROWPAR
+#define DMC_ROWPAR 1
 #endif
-constexpr bool M_LDS = !BIGMAT && DMC_M_LDS != 0 && NM > 0 &&
-                       NM*REC_BYTES + 4*(RW + CW)*REC_BYTES <= DMC_LDS_BUDGET;
-constexpr int MAT_LDS_WORDS = (MAT_IN_LDS || M_LDS) ? NM : 0;
-constexpr int REC_BUDGET = DMC_LDS_BUDGET - MAT_LDS_WORDS*REC_BYTES;
-constexpr int LDS_CONS_WANT0 = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
-constexpr int LDS_CONS_WANT = MAT_IN_LDS && LDS_CONS_WANT0 > 6 ? 6 : LDS_CONS_WANT0;
+constexpr int REC_BYTES = LANES*(int)sizeof(real);    // one record word, all lanes
+// exchange buffer of the row-parallel solver, [word][env]:
+//   EB_VEC (NV)  per-env vector the row lanes read (warm start / search direction)
+//   EB_ALPHA, EB_ACTIVE   step to apply / env still iterating
+//   EB_ACC (NM + NV + 1)  per-env sums: Hessian terms, constraint force, number
+//                         of active-set changes (the warm-start and line-search
+//                         passes use the first few; the warm-start pass also
+//                         parks qacc_smooth in words 2 .. 2 + NV)
+constexpr int EB_VEC = 0, EB_ALPHA = NV, EB_ACTIVE = NV + 1, EB_ACC = NV + 2;
+constexpr int EB_NACC = NM + NV + 1;
+constexpr int EB_WORDS_ = EB_ACC + EB_NACC;
+// (needs room for the buffer plus at least two row rounds and two contacts)
+constexpr bool ROWPAR = DMC_ROWPAR != 0 && NV > 0 && NEFC_MAX > 0 &&
+                        (EB_WORDS_ + 2*(NV + 5) + 2*CW)*REC_BYTES <= DMC_LDS_BUDGET;
+constexpr int EB_WORDS = ROWPAR ? EB_WORDS_ : 0;
+constexpr int RW = NV + 4 + (ROWPAR ? 1 : 0);
+enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3, ROW_ENV = NV + 4 };
+constexpr int REC_BUDGET = DMC_LDS_BUDGET - EB_WORDS*REC_BYTES;
+constexpr int LDS_CONS_WANT = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
 constexpr int LDS_CONS_FIT = (REC_BUDGET/2)/(CW*REC_BYTES);   // <= half the budget
 constexpr int LDS_CONS = LDS_CONS_WANT < LDS_CONS_FIT ? LDS_CONS_WANT : LDS_CONS_FIT;
 constexpr int LDS_ROWS_FIT = (REC_BUDGET - LDS_CONS*CW*REC_BYTES)/(RW*REC_BYTES);
@@ -406,71 +370,101 @@ constexpr int LDS_ROWS = LDS_ROWS_FIT < NEFC_MAX ? LDS_ROWS_FIT : NEFC_MAX;
 static_assert(LDS_CONS >= 0 && LDS_ROWS >= 0, "LDS budget arithmetic");
 constexpr int GLB_ROWS = NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 0;
 constexpr int GLB_CONS = NCON_MAX - LDS_CONS > 0 ? NCON_MAX - LDS_CONS : 0;
-enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3 };
 
 struct LdsRow {
   real* p;
   __device__ __forceinline__ real get(int k) const { return p[k*LANES]; }
   __device__ __forceinline__ void set(int k, real v) const { p[k*LANES] = v; }
 };
-struct GlbRow {
+struct GlbRow {   // overflow rows: [round][word][slot], per workgroup
+  real* p;
+  __device__ __forceinline__ real get(int k) const { return p[k*LANES]; }
+  __device__ __forceinline__ void set(int k, real v) const { p[k*LANES] = v; }
+};
+struct GlbCon {   // overflow contacts: [word][env]
   real* p; long long n;
   __device__ __forceinline__ real get(int k) const { return p[k*n]; }
   __device__ __forceinline__ void set(int k, real v) const { p[k*n] = v; }
 };
-// workspace words per env: overflow rows, overflow contacts, then (big-matrix
-// mode) M and, if it did not fit in LDS, the factor/Hessian buffer
-constexpr int WS_MAT_M = GLB_ROWS*RW + GLB_CONS*CW;
-constexpr int WS_MAT_L = WS_MAT_M + (BIGMAT ? NM : 0);
-constexpr int WS_WORDS = WS_MAT_L + (BIGMAT && !MAT_IN_LDS ? NM : 0);
+// workspace words per env: overflow rows (the workgroup's block of
+// GLB_ROWS*RW*LANES words, i.e. GLB_ROWS*RW per env), overflow contacts, then
+// (-DDMC_STATE_COMP) the low words of the fp64 state:
+// qpos/qvel are then carried between steps as fp64 values split into the public
+// fp32 field (high word) and a low word kept here together with the high word
+// it belongs to (a field overwritten from outside -- set_state, reset -- no
+// longer matches its tag and the low word is dropped).
+// The host allocates ws_per_env words for the batch size rounded up to whole
+// workgroups.
+constexpr int WS_CONS = GLB_ROWS*RW;
+constexpr int WS_COMP = WS_CONS + GLB_CONS*CW;
+#ifdef DMC_STATE_COMP
+constexpr int WS_WORDS = WS_COMP + 2*(NQ + NV);
+#else
+constexpr int WS_WORDS = WS_COMP;
+#endif
 
 struct Work {
-  real* lds;   // LDS base + lane (rows, contact records, then the matrix buffer)
-  real* glb;   // workspace base + env
-  long long nenv;
-  __device__ __forceinline__ GlbMat matM() const { return GlbMat{glb + (long long)WS_MAT_M*nenv, nenv}; }
-  __device__ __forceinline__ LdsMat matL_lds() const { return LdsMat{lds + (LDS_ROWS*RW + LDS_CONS*CW)*LANES}; }
-  __device__ __forceinline__ GlbMat matL_glb() const { return GlbMat{glb + (long long)WS_MAT_L*nenv, nenv}; }
-  __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*LANES}; }
-  __device__ __forceinline__ GlbRow grow(int r) const {
-    return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
+  real* lds0;     // LDS base of the workgroup: row rounds, contacts, exchange buffer
+  real* glb_rows; // overflow row rounds of this workgroup
+  real* glb;      // per-env workspace base + env ([idx][npad] layout)
+  long long npad; // envs rounded up to whole workgroups (stride of `glb`)
+  int lane;
+  int base;       // ROWPAR: first slot of this lane's env; else unused
+  int cnt;        // ROWPAR: number of rows this env will build
+  int total;      // ROWPAR: rows of the whole workgroup (wave-uniform)
+  // slot s of the row store
+  __device__ __forceinline__ bool in_lds(int s) const {
+    return LDS_ROWS >= NEFC_MAX || (s >> 6) < LDS_ROWS;
+  }
+  __device__ __forceinline__ LdsRow lslot(int s) const {
+    return LdsRow{lds0 + (s >> 6)*RW*LANES + (s & 63)};
+  }
+  __device__ __forceinline__ GlbRow gslot(int s) const {
+    return GlbRow{glb_rows + ((s >> 6) - LDS_ROWS)*RW*LANES + (s & 63)};
+  }
+  // slot of row r of this lane's env
+  __device__ __forceinline__ int slot(int r) const {
+    return ROWPAR ? base + r : r*LANES + lane;
   }
   __device__ __forceinline__ LdsRow lcon(int k) const {
-    return LdsRow{lds + (LDS_ROWS*RW + k*CW)*LANES};
+    return LdsRow{lds0 + (LDS_ROWS*RW + k*CW)*LANES + lane};
   }
-  __device__ __forceinline__ GlbRow gcon(int k) const {
-    return GlbRow{glb + ((long long)GLB_ROWS*RW + (long long)(k - LDS_CONS)*CW)*nenv, nenv};
+  __device__ __forceinline__ GlbCon gcon(int k) const {
+    return GlbCon{glb + ((long long)WS_CONS + (long long)(k - LDS_CONS)*CW)*npad, npad};
+  }
+  __device__ __forceinline__ real* eb(int word) const {   // exchange buffer, this lane's env
+    return lds0 + (LDS_ROWS*RW + LDS_CONS*CW + word)*LANES + lane;
+  }
+  __device__ __forceinline__ real* eb_of(int word, int env) const {
+    return lds0 + (LDS_ROWS*RW + LDS_CONS*CW + word)*LANES + env;
   }
 };
-constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW + MAT_LDS_WORDS > 0
-                           ? LDS_ROWS*RW + LDS_CONS*CW + MAT_LDS_WORDS : 1)*LANES;
-// f(row handle) for rows [0, nefc): LDS tier first, then the HBM tier
+constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW + EB_WORDS > 0
+                           ? LDS_ROWS*RW + LDS_CONS*CW + EB_WORDS : 1)*LANES;
+// f(row handle) for this lane's rows [0, nefc)
 template <class F>
 static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) {
-  const int n1 = nefc < LDS_ROWS ? nefc : LDS_ROWS;
-  DMC_ROW_UNROLL_PRAGMA
-  for (int r = 0; r < n1; r++) f(W.lrow(r));
-  if (LDS_ROWS < NEFC_MAX)
-    for (int r = LDS_ROWS; r < nefc; r++) f(W.grow(r));
+  for (int r = 0; r < nefc; r++) {
+    const int s = W.slot(r);
+    if (W.in_lds(s)) f(W.lslot(s)); else f(W.gslot(s));
+  }
+}
+// f(row handle) for every slot of the workgroup, one slot per lane and round
+// (ROWPAR; `total` is wave-uniform, so the tier test is a scalar branch)
+template <class F>
+static __device__ __forceinline__ void for_slots(const Work& W, F&& f) {
+  const int rounds = (W.total + LANES - 1)/LANES;
+  for (int k = 0; k < rounds; k++) {
+    const int s = k*LANES + W.lane;
+    if (LDS_ROWS >= NEFC_MAX || k < LDS_ROWS) { if (s < W.total) f(W.lslot(s)); }
+    else { if (s < W.total) f(W.gslot(s)); }
+  }
 }
 
-// which storage backs M and the factor/Hessian buffer in this build
-template <bool Big> struct MatSel;
-template <> struct MatSel<false> {
-  static __device__ __forceinline__ auto M(Env& E, const Work& W) {
-    if constexpr (M_LDS) return W.matL_lds(); else return RegMat{E.qM};
-  }
+struct Mats {
+  static __device__ __forceinline__ RegMat M(Env& E, const Work&) { return RegMat{E.qM}; }
   static __device__ __forceinline__ RegMat L(Env& E, const Work&) { return RegMat{E.qL}; }
 };
-template <> struct MatSel<true> {
-  static __device__ __forceinline__ GlbMat M(Env&, const Work& W) { return W.matM(); }
-#if 1
-  static __device__ __forceinline__ auto L(Env&, const Work& W) {
-    if constexpr (MAT_IN_LDS) return W.matL_lds(); else return W.matL_glb();
-  }
-#endif
-};
-using Mats = MatSel<BIGMAT>;
 
 // ---------------------------------------------------------------------------
 // position stage: kinematics, centre-of-mass frame, composite inertia
@@ -892,13 +886,34 @@ DEV void write_row(const Row& rec, const Env& E, const real* row, real pm,
 }
 DEV bool push_row(Env& E, const Work& W, const real* row, real pos_minus_margin,
                   real K, real B, real imp, real Rrow) {
-  if (E.nefc >= NEFC_MAX) { E.warn |= WARN_CNSTRFULL; return false; }
-  const int r = E.nefc++;
-  if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS)
-    write_row(W.lrow(r), E, row, pos_minus_margin, K, B, imp, Rrow);
-  else
-    write_row(W.grow(r), E, row, pos_minus_margin, K, B, imp, Rrow);
+  // ROWPAR: W.cnt (count_rows) is what this env reserved in the packed store
+  if (E.nefc >= (ROWPAR ? W.cnt : NEFC_MAX)) { E.warn |= WARN_CNSTRFULL; return false; }
+  const int s = W.slot(E.nefc++);
+  if (W.in_lds(s)) {
+    const LdsRow rec = W.lslot(s);
+    write_row(rec, E, row, pos_minus_margin, K, B, imp, Rrow);
+    if (ROWPAR) rec.set(ROW_ENV, (real)W.lane);
+  } else {
+    const GlbRow rec = W.gslot(s);
+    write_row(rec, E, row, pos_minus_margin, K, B, imp, Rrow);
+    if (ROWPAR) rec.set(ROW_ENV, (real)W.lane);
+  }
   return true;
+}
+
+// rows limit_rows() will build (ROWPAR reserves slots before building)
+DEV int count_limit_rows(const Env& E) {
+  if (DISABLEFLAGS & (DSBL_LIMIT | DSBL_CONSTRAINT)) return 0;
+  int n = 0;
+  DMC_UNROLL
+  for (int l = 0; l < NLIMIT; l++) {
+    const int j = limit_jnt[l], qa = jnt_qposadr[j];
+    const real margin = R(jnt_margin[j]);
+    const real q = E.qpos[qa];
+    n += (q - R(jnt_range[2*j]) < margin) ? 1 : 0;
+    n += (R(jnt_range[2*j + 1]) - q < margin) ? 1 : 0;
+  }
+  return n;
 }
 
 DEV void limit_rows(Env& E, const Work& W) {
@@ -1251,8 +1266,22 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
   }
 }
 
+// rows contact_rows() will build from the contact list
+template <class Rec>
+DEV int rows_of_contact_count(const Rec& rec) {
+  const int p = (int)rec.get(10);
+  return rec.get(9) < pair_includemargin[p] ? pair_nrow[p] : 0;
+}
+DEV int count_contact_rows(const Env& E, const Work& W) {
+  int n = 0;
+  const int n1 = E.ncon < LDS_CONS ? E.ncon : LDS_CONS;
+  for (int k = 0; k < n1; k++) n += rows_of_contact_count(W.lcon(k));
+  if (LDS_CONS < NCON_MAX)
+    for (int k = LDS_CONS; k < E.ncon; k++) n += rows_of_contact_count(W.gcon(k));
+  return n;
+}
+
 DEV void contact_rows(Env& E, const Work& W) {
-  detect_contacts(E, W);
   const int n1 = E.ncon < LDS_CONS ? E.ncon : LDS_CONS;
   for (int k = 0; k < n1; k++) rows_of_contact(E, W, W.lcon(k));
   if (LDS_CONS < NCON_MAX)
@@ -1270,7 +1299,6 @@ DEV void ls_eval(LsPoint& P, real alpha, const Env& E, const Work& W, real q1, r
   real d0 = 2*alpha*q2 + q1, d1 = 2*q2;
   for_rows(W, E.nefc, [&](auto rec) {
     const real x0 = rec.get(ROW_JAR), v = rec.get(ROW_JV), D = rec.get(ROW_D);
-    DMC_SCHED_FENCE();
     const real x = x0 + alpha*v;
     const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
     dcost += R(0.5)*D*(a*a - a0*a0);
@@ -1295,7 +1323,7 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
   const auto M = Mats::M(E, W);
   // small mode: Hessian in registers; big mode: it reuses the factor buffer
   // (the factor of M is dead once qacc_smooth has been solved)
-  const auto H = [&]() { if constexpr (BIGMAT) return Mats::L(E, W); else return RegMat{Hreg}; }();
+  const RegMat H{Hreg};
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
   symv(Ma, M, E.qacc);
@@ -1317,8 +1345,7 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
       real row[NVX];
       DMC_UNROLL
       for (int j = 0; j < NV; j++) row[j] = rec.get(j);
-      DMC_SCHED_FENCE();
-      if (iter > 0) {
+        if (iter > 0) {
         const real x1 = jar + alpha_prev*jv;
         changed |= (jar < 0) != (x1 < 0);
         rec.set(ROW_JAR, x1);
@@ -1376,8 +1403,7 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
         DMC_UNROLL
         for (int j = 0; j < NV; j++) row[j] = rec.get(j);
         const real x0 = rec.get(ROW_JAR), D = rec.get(ROW_D);
-        DMC_SCHED_FENCE();
-        real sacc = 0;
+            real sacc = 0;
         DMC_UNROLL
         for (int j = 0; j < NV; j++) sacc += row[j]*search[j];
         rec.set(ROW_JV, sacc);
@@ -1420,14 +1446,295 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
 }
 
 // ---------------------------------------------------------------------------
+// Row-parallel form of the same solver (ROWPAR): the per-env algorithm above,
+// unchanged, but every pass over the constraint rows is executed by the whole
+// wavefront over the packed row store (for_slots: one row per lane and round,
+// whatever env it belongs to), and what the pass sums per env goes through LDS
+// float atomics into the env's words of the exchange buffer.  Env-indexed
+// work (Cholesky, step acceptance, stopping rules) stays one env per lane.
+// Cost per pass: ceil(rows of the wave / 64) rounds, not max_env(rows) rounds.
+// ---------------------------------------------------------------------------
+#ifndef DMC_HOST_SHIM
+// lanes of the (single-wave) workgroup hand LDS data over: the LDS queue is in
+// order within a wave, the fences pin the compiler and drain the counters
+DEV void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+DEV bool wany(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+DEV int wshfl_up(int v, int d) { return __shfl_up(v, d, 64); }
+DEV int wbcast(int v, int src) { return __shfl(v, src, 64); }
+DEV void lds_add(real* p, real v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#endif
+// read an accumulator and leave it zero for the next pass
+DEV real take(real* p) { const real v = *p; *p = 0; return v; }
+
+// exclusive prefix sum of `cnt` over the lanes of the workgroup -> packed slots
+DEV void reserve_rows(Work& W, int cnt) {
+  int incl = cnt;
+  DMC_UNROLL
+  for (int d = 1; d < LANES; d <<= 1) {
+    const int t = wshfl_up(incl, d);
+    if (W.lane >= d) incl += t;
+  }
+  W.cnt = cnt;
+  W.base = incl - cnt;
+  W.total = wbcast(incl, LANES - 1);
+}
+
+// warm start: cost of the previous qacc against the unconstrained acceleration;
+// leaves Jaref of the warm start in ROW_JAR and of qacc_smooth in ROW_JV and
+// returns whether the warm start is used (the first pass A of the solver moves
+// ROW_JV into ROW_JAR for the envs that start from qacc_smooth)
+DEV bool warmstart_rp(Env& E, const Work& W, bool has_rows) {
+  const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
+  real cw = 0;
+  if (try_warm && has_rows) {
+    real Ma[NVX];
+    symv(Ma, RegMat{E.qM}, E.warm);
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++)
+      cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
+  }
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) {
+    *W.eb(EB_VEC + i) = E.warm[i];
+    *W.eb(EB_ACC + 2 + i) = E.qacc_smooth[i];
+  }
+  wsync();
+  for_slots(W, [&](auto rec) {
+    const int e = (int)rec.get(ROW_ENV);
+    real row[NVX];
+    DMC_UNROLL
+    for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+    const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
+    real jw = 0, js = 0;
+    DMC_UNROLL
+    for (int j = 0; j < NV; j++) {
+      jw += row[j]*(*W.eb_of(EB_VEC + j, e));
+      js += row[j]*(*W.eb_of(EB_ACC + 2 + j, e));
+    }
+    jw -= aref; js -= aref;
+    rec.set(ROW_JAR, jw); rec.set(ROW_JV, js);
+    // (the sums land in words 0 and 1; qacc_smooth is parked from word 2 on)
+    if (jw < 0) lds_add(W.eb_of(EB_ACC, e), R(0.5)*D*jw*jw);
+    if (js < 0) lds_add(W.eb_of(EB_ACC + 1, e), R(0.5)*D*js*js);
+  });
+  wsync();
+  cw += take(W.eb(EB_ACC));
+  const real cs = take(W.eb(EB_ACC + 1));
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) *W.eb(EB_ACC + 2 + i) = 0;
+  return try_warm && !(cw > cs);
+}
+
+DEV void solve_newton_rp(Env& E, const Work& W, real tol, bool active, bool use_warm) {
+#ifdef DMC_SOLVER_PROFILE
+  long long tl_ = wall_clock64();
+#endif
+  real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], Hreg[MAT_REGS];
+  const RegMat M{E.qM};
+  const RegMat H{Hreg};
+  const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
+  symv(Ma, M, E.qacc);
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) { Mv[i] = 0; search[i] = 0; }
+  real improvement = 0, alpha_prev = 0, q1 = 0, q2 = 0, gtol = 0;
+  for (int iter = 0;; iter++) {      // `iter` is the same for every env still active
+    // at iter 0 the "step" word selects the starting point instead: != 0 means
+    // Jaref <- the qacc_smooth candidate parked in ROW_JV
+    *W.eb(EB_ALPHA) = iter == 0 ? (use_warm ? R(0) : R(1)) : alpha_prev;
+    *W.eb(EB_ACTIVE) = active ? R(1) : R(0);
+    wsync();
+    // pass A: apply the previous step to Jaref, note active-set changes,
+    // accumulate constraint force and Hessian terms of the active rows
+    for_slots(W, [&](auto rec) {
+      const int e = (int)rec.get(ROW_ENV);
+      if (*W.eb_of(EB_ACTIVE, e) == 0) return;
+      real jar = rec.get(ROW_JAR);
+      const real jv = rec.get(ROW_JV), D = rec.get(ROW_D);
+      const real al = *W.eb_of(EB_ALPHA, e);
+      real row[NVX];
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+      if (iter == 0) {
+        if (al != 0) { jar = jv; rec.set(ROW_JAR, jar); }
+      } else {
+        const real x1 = jar + al*jv;
+        if ((jar < 0) != (x1 < 0)) lds_add(W.eb_of(EB_ACC + NM + NV, e), R(1));
+        rec.set(ROW_JAR, x1);
+        jar = x1;
+      }
+      if (jar < 0) {
+        const real f = -D*jar;
+        DMC_UNROLL
+        for (int j = 0; j < NV; j++) {
+          lds_add(W.eb_of(EB_ACC + NM + j, e), row[j]*f);
+          const real s = D*row[j];
+          DMC_UNROLL
+          for (int k = 0; k <= j; k++) lds_add(W.eb_of(EB_ACC + tri(j, k), e), s*row[k]);
+        }
+      }
+    });
+    wsync();
+    SPROF(0);
+    if (active) {
+      DMC_UNROLL
+      for (int i = 0; i < NM; i++) H.set(i, M.get(i) + take(W.eb(EB_ACC + i)));
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = take(W.eb(EB_ACC + NM + i));
+      const bool changed = take(W.eb(EB_ACC + NM + NV)) != 0;
+      // fp32: after a full step that left the active set unchanged the iterate
+      // is the exact minimiser of the current quadratic piece
+      const bool converged = DMC_F32_RULES && iter > 0 && !changed &&
+                             fabs(alpha_prev - 1) < R(1e-3);
+      real gn = 0;
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) {
+        grad[i] = Ma[i] - E.qfrc_smooth[i] - E.qfrc_constraint[i];
+        gn += grad[i]*grad[i];
+      }
+      if ((iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) ||
+          iter >= ITERATIONS) {
+        active = false; E.iters = iter;
+      } else {
+        chol_factor(H);
+        DMC_UNROLL
+        for (int i = 0; i < NV; i++) search[i] = -grad[i];
+        chol_solve(search, H);
+        real sn = 0;
+        DMC_UNROLL
+        for (int i = 0; i < NV; i++) sn += search[i]*search[i];
+        sn = sqrt(sn);
+        alpha_prev = 0;
+        if (sn < DMC_MINVAL) {
+          active = false; E.iters = iter;
+        } else {
+          gtol = tol*R(0.01)*sn/scale;
+          symv(Mv, M, search);
+          q1 = 0; q2 = 0;
+          DMC_UNROLL
+          for (int i = 0; i < NV; i++) {
+            q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
+            q2 += R(0.5)*search[i]*Mv[i];
+            *W.eb(EB_VEC + i) = search[i];
+          }
+        }
+      }
+    }
+    SPROF(1);
+    if (!wany(active)) break;
+    *W.eb(EB_ACTIVE) = active ? R(1) : R(0);
+    wsync();
+    // pass B: Jv, and the derivatives of the cost along `search` at alpha = 0
+    for_slots(W, [&](auto rec) {
+      const int e = (int)rec.get(ROW_ENV);
+      if (*W.eb_of(EB_ACTIVE, e) == 0) return;
+      real row[NVX];
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+      const real x0 = rec.get(ROW_JAR), D = rec.get(ROW_D);
+      real sacc = 0;
+      DMC_UNROLL
+      for (int j = 0; j < NV; j++) sacc += row[j]*(*W.eb_of(EB_VEC + j, e));
+      rec.set(ROW_JV, sacc);
+      if (x0 < 0) {
+        lds_add(W.eb_of(EB_ACC, e), D*x0*sacc);
+        lds_add(W.eb_of(EB_ACC + 1, e), D*sacc*sacc);
+      }
+    });
+    wsync();
+    SPROF(2);
+    // exact line search: safeguarded Newton on the directional derivative,
+    // every env with its own bracket; one pass over the rows per evaluation
+    LsPoint p0, p, best;
+    real lo = 0, hi = 0, a = 0, dtol = 0;
+    bool have_hi = false, ls = false;
+    p0.alpha = 0; p0.dcost = 0; p0.d0 = 0; p0.d1 = 1;
+    best = p0;
+    if (active) {
+      p0.d0 = q1 + take(W.eb(EB_ACC));
+      const real d1 = 2*q2 + take(W.eb(EB_ACC + 1));
+      p0.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+      if (!(p0.d0 < 0)) {
+        active = false; E.iters = iter;
+      } else {
+        best = p0;
+        a = -p0.d0/p0.d1;
+        dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
+        ls = true;
+      }
+    }
+    for (int it = 0; it < DMC_LS_MAXIT; it++) {
+      if (!wany(ls)) break;
+      *W.eb(EB_ALPHA) = a;
+      *W.eb(EB_ACTIVE) = ls ? R(1) : R(0);
+      wsync();
+      for_slots(W, [&](auto rec) {
+        const int e = (int)rec.get(ROW_ENV);
+        if (*W.eb_of(EB_ACTIVE, e) == 0) return;
+        const real x0 = rec.get(ROW_JAR), v = rec.get(ROW_JV), D = rec.get(ROW_D);
+        const real x = x0 + (*W.eb_of(EB_ALPHA, e))*v;
+        const real xa = x < 0 ? x : R(0), xa0 = x0 < 0 ? x0 : R(0);
+        if (x < 0 || x0 < 0) lds_add(W.eb_of(EB_ACC, e), R(0.5)*D*(xa*xa - xa0*xa0));
+        if (x < 0) {
+          lds_add(W.eb_of(EB_ACC + 1, e), D*x*v);
+          lds_add(W.eb_of(EB_ACC + 2, e), D*v*v);
+        }
+      });
+      wsync();
+      if (ls) {
+        p.alpha = a;
+        p.dcost = a*a*q2 + a*q1 + take(W.eb(EB_ACC));
+        p.d0 = 2*a*q2 + q1 + take(W.eb(EB_ACC + 1));
+        const real d1 = 2*q2 + take(W.eb(EB_ACC + 2));
+        p.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+        if (p.dcost < best.dcost) best = p;
+        if (fabs(p.d0) < dtol) {
+          ls = false;
+        } else {
+          if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
+          real an = a - p.d0/p.d1;
+          if (have_hi) {
+            if (!(an > lo && an < hi)) an = R(0.5)*(lo + hi);
+            if (hi - lo < R(1e-6)*hi) ls = false;
+          } else if (an <= lo) {
+            an = 2*a;
+          }
+          if (ls) a = an;
+        }
+      }
+    }
+    SPROF(3);
+    if (active) {
+      const real alpha = best.alpha;
+      if (alpha == 0) {
+        active = false; E.iters = iter;
+      } else {
+        improvement = -best.dcost;
+        DMC_UNROLL
+        for (int i = 0; i < NV; i++) { E.qacc[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
+        alpha_prev = alpha;           // applied to Jaref by the next pass A
+      }
+    }
+    SPROF(4);
+    if (!wany(active)) break;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // touch sensors (mjSENS_TOUCH in mj_sensorAcc): sum of the normal forces of the
 // contacts that involve the sensor site's body and whose force ray, cast from
 // the contact point, meets the site's spherical zone
 // ---------------------------------------------------------------------------
 DEV real row_force(const Work& W, int r) {
   real jar, D;
-  if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS) { jar = W.lrow(r).get(ROW_JAR); D = W.lrow(r).get(ROW_D); }
-  else { jar = W.grow(r).get(ROW_JAR); D = W.grow(r).get(ROW_D); }
+  const int s = W.slot(r);
+  if (W.in_lds(s)) { jar = W.lslot(s).get(ROW_JAR); D = W.lslot(s).get(ROW_D); }
+  else { jar = W.gslot(s).get(ROW_JAR); D = W.gslot(s).get(ROW_D); }
   return jar < 0 ? -D*jar : R(0);
 }
 // smallest t >= 0 with |o + t d| = radius (d unit), or -1
@@ -1485,26 +1792,56 @@ DEV void touch_sensors(Env& E, const Work& W) {
     for (int k = LDS_CONS; k < E.ncon; k++) touch_of_contact(E, W, W.gcon(k), r);
 }
 
-// forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms
-DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
+// forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms.
+// ROWPAR: called by every lane of the workgroup at the same point (the solver
+// passes are executed by the whole wavefront); `rows_ok` false keeps this env
+// out of the constraint stage (surplus lanes of a partial last workgroup).
+DEV void forward(Env& E, Work& W, bool actuation, real tol, bool rows_ok = true) {
   kinematics(E);
   com_pos(E);
   crb_factor(E, W);
   com_vel(E);
   smooth_forces(E, W, actuation);
   E.ncon = 0; E.nefc = 0; E.iters = 0;
+#ifdef DMC_ABLATE_CONTACT
+  const bool with_contacts = false;
+#else
+  const bool with_contacts = NPAIR > 0;
+#endif
+  if (with_contacts) detect_contacts(E, W);
+  if (ROWPAR) {
+    // reserve this env's slots in the packed row store before building rows
+    int cnt = count_limit_rows(E) + (with_contacts ? count_contact_rows(E, W) : 0);
+    if (cnt > NEFC_MAX) cnt = NEFC_MAX;
+    reserve_rows(W, rows_ok ? cnt : 0);
+  }
   limit_rows(E, W);
   E.nefc_limit = E.nefc;
-#ifndef DMC_ABLATE_CONTACT
-  if (NPAIR > 0) contact_rows(E, W);
-#endif
+  if (with_contacts) contact_rows(E, W);
+  if (ROWPAR) {
+    // (count_* mirror the builders; should they ever disagree, keep the store consistent)
+    real zero[NVX];
+    DMC_UNROLL
+    for (int j = 0; j < NV; j++) zero[j] = 0;
+    while (E.nefc < W.cnt) push_row(E, W, zero, 0, 0, 0, 0, R(1e30));
+    if (E.nefc_limit > E.nefc) E.nefc_limit = E.nefc;
+  }
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
 #ifdef DMC_ABLATE_SOLVER
-  if (true) {
+  const bool solve = false;
 #else
-  if (E.nefc == 0) {
+  const bool solve = true;
 #endif
+  if (ROWPAR && solve) {
+    const bool has_rows = E.nefc > 0;
+    bool use_warm = false;
+    if (W.total > 0) use_warm = warmstart_rp(E, W, has_rows);   // wave-uniform branch
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++)
+      E.qacc[i] = has_rows && use_warm ? E.warm[i] : E.qacc_smooth[i];
+    if (W.total > 0) solve_newton_rp(E, W, tol, has_rows, use_warm);
+  } else if (E.nefc == 0 || !solve) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qacc[i] = E.qacc_smooth[i];
   } else {
@@ -1523,7 +1860,6 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
       DMC_UNROLL
       for (int j = 0; j < NV; j++) row[j] = rec.get(j);
       const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
-      DMC_SCHED_FENCE();
       real jw = 0, js = 0;
       DMC_UNROLL
       for (int j = 0; j < NV; j++) { jw += row[j]*E.warm[j]; js += row[j]*E.qacc_smooth[j]; }
@@ -1564,6 +1900,44 @@ DEV void integrate_pos(real* qpos, const real* qvel, real h) {
   }
 }
 
+#ifdef DMC_STATE_COMP
+// State update in fp64 on (high, low) fp32 pairs: qvel = v0 + h*acc, then
+// qpos = q0 + h*(dq or the new qvel); quaternions keep the fp32 path.  Writes
+// E.qvel/E.qpos and their low words.
+DEV void integrate_comp(Env& E, const real* v0, const real* v0_lo, const real* q0,
+                        const real* q0_lo, const real* acc, const real* dq) {
+  const double h = timestep;
+  double v[NVX];
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) {
+    v[i] = (double)v0[i] + (double)v0_lo[i] + h*(double)acc[i];
+    const real hi = (real)v[i];
+    E.qvel[i] = hi; E.qvel_lo[i] = (real)(v[i] - (double)hi);
+  }
+  real qn[NQ > 0 ? NQ : 1], rate[NVX];
+  DMC_UNROLL
+  for (int i = 0; i < NQ; i++) qn[i] = q0[i];
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) rate[i] = dq ? dq[i] : E.qvel[i];
+  integrate_pos(qn, rate, R(timestep));          // quaternion parts
+  DMC_UNROLL
+  for (int j = 0; j < NJNT; j++) {
+    const int qa = jnt_qposadr[j], da = jnt_dofadr[j];
+    const int n = jnt_type[j] == JNT_FREE ? 3 : (jnt_type[j] == JNT_BALL ? 0 : 1);
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      if (k >= n) continue;
+      const double r = dq ? (double)dq[da + k] : v[da + k];
+      const double q = (double)q0[qa + k] + (double)q0_lo[qa + k] + h*r;
+      const real hi = (real)q;
+      qn[qa + k] = hi; E.qpos_lo[qa + k] = (real)(q - (double)hi);
+    }
+  }
+  DMC_UNROLL
+  for (int i = 0; i < NQ; i++) E.qpos[i] = qn[i];
+}
+#endif
+
 DEV void reset_state(Env& E, real& time) {   // mj_resetData
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) E.qpos[i] = R(qpos0[i]);
@@ -1571,6 +1945,12 @@ DEV void reset_state(Env& E, real& time) {   // mj_resetData
   for (int i = 0; i < NV; i++) { E.qvel[i] = 0; E.warm[i] = 0; }
   DMC_UNROLL
   for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
+#ifdef DMC_STATE_COMP
+  DMC_UNROLL
+  for (int i = 0; i < NQ; i++) E.qpos_lo[i] = 0;
+  DMC_UNROLL
+  for (int i = 0; i < NV; i++) E.qvel_lo[i] = 0;
+#endif
   time = 0;
 }
 DEV bool check_state(Env& E, real& time) {   // mj_checkPos / mj_checkVel
@@ -1585,11 +1965,26 @@ DEV bool check_state(Env& E, real& time) {   // mj_checkPos / mj_checkVel
 }
 
 // one `Physics.step()`: finish the step from the current state
-DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
+// `stale`: the acceleration is computed from the position/velocity stage of the
+// reset state (qpos0, zero velocity) and applied to the current state.  That is
+// what the reference's cheetah does in the first of its 200 settle steps:
+// reset_context runs mj_forward at qpos0, initialize_episode overwrites qpos
+// without a forward pass and calls physics.step(), whose mj_step2 still sees
+// the mass matrix, bias forces and contacts of qpos0 (suite/cheetah.py:63-77,
+// engine.py:149-166).
+DEV void physics_step(Env& E, Work& W, real& time, real tol, bool rows_ok,
+                      bool stale = false) {
   const real h = R(timestep);
   check_state(E, time);
   if (INTEGRATOR == 0) {
-    forward(E, W, true, tol);
+    real qkeep[NQ > 0 ? NQ : 1], vkeep[NVX];
+    if (stale) {
+      DMC_UNROLL
+      for (int i = 0; i < NQ; i++) { qkeep[i] = E.qpos[i]; E.qpos[i] = R(qpos0[i]); }
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) { vkeep[i] = E.qvel[i]; E.qvel[i] = 0; }
+    }
+    forward(E, W, true, tol, rows_ok);
     bool ba = false;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) ba |= bad(E.qacc[i]);
@@ -1601,7 +1996,7 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
     if (damped) {
       real Areg[MAT_REGS];
       const auto M = Mats::M(E, W);
-      const auto A = [&]() { if constexpr (BIGMAT) return Mats::L(E, W); else return RegMat{Areg}; }();
+      const RegMat A{Areg};
       DMC_UNROLL
       for (int i = 0; i < NM; i++) A.set(i, M.get(i));
       DMC_UNROLL
@@ -1615,17 +2010,19 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
       DMC_UNROLL
       for (int i = 0; i < NV; i++) qacc[i] = E.qacc[i];
     }
-#ifdef DMC_DEBUG_EULER_QACC
-    DMC_UNROLL
-    for (int i = 0; i < NV; i++) E.qacc[i] = qacc[i];
-#endif
-#ifdef DMC_DEBUG_EULER_RHS
-    DMC_UNROLL
-    for (int i = 0; i < NV; i++) E.qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
-#endif
+    if (stale) {
+      DMC_UNROLL
+      for (int i = 0; i < NQ; i++) E.qpos[i] = qkeep[i];
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) E.qvel[i] = vkeep[i];
+    }
+#ifdef DMC_STATE_COMP
+    integrate_comp(E, E.qvel, E.qvel_lo, E.qpos, E.qpos_lo, qacc, nullptr);
+#else
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qvel[i] += h*qacc[i];
     integrate_pos(E.qpos, E.qvel, h);
+#endif
     time += h;
   } else {
     // RK4 (tableau and stage handling as SURVEY.md Appendix A)
@@ -1635,11 +2032,19 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
     for (int i = 0; i < NQ; i++) q0[i] = E.qpos[i];
     DMC_UNROLL
     for (int i = 0; i < NV; i++) v0[i] = E.qvel[i];
-    forward(E, W, true, tol);
+    forward(E, W, true, tol, rows_ok);
     bool ba = false;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) ba |= bad(E.qacc[i]);
-    if (ba) { E.warn |= WARN_BADQACC; reset_state(E, time); return; }
+    // a bad acceleration resets the state; the lane still walks through the
+    // remaining stages (every lane takes part in the solver passes of forward)
+    if (ba) {
+      E.warn |= WARN_BADQACC; reset_state(E, time);
+      DMC_UNROLL
+      for (int i = 0; i < NQ; i++) q0[i] = E.qpos[i];
+      DMC_UNROLL
+      for (int i = 0; i < NV; i++) { v0[i] = 0; E.qacc[i] = 0; }
+    }
     DMC_UNROLL
     for (int i = 0; i < NV; i++) { Fv[i] = E.qvel[i]; Fa[i] = E.qacc[i]; }
     const real Acoef[3] = {R(0.5), R(0.5), R(1)};
@@ -1654,10 +2059,20 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
       DMC_UNROLL
       for (int i = 0; i < NQ; i++) E.qpos[i] = q0[i];
       integrate_pos(E.qpos, dv, h);
-      forward(E, W, true, tol);
+      forward(E, W, true, tol, rows_ok);
       DMC_UNROLL
       for (int i = 0; i < NV; i++) { Fv[s*NV + i] = E.qvel[i]; Fa[s*NV + i] = E.qacc[i]; }
     }
+    if (ba) { reset_state(E, time); return; }
+#ifdef DMC_STATE_COMP
+    real acc[NVX];
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) {
+      dv[i] = (Fv[i] + 2*Fv[NV + i] + 2*Fv[2*NV + i] + Fv[3*NV + i])*R(1.0/6.0);
+      acc[i] = (Fa[i] + 2*Fa[NV + i] + 2*Fa[2*NV + i] + Fa[3*NV + i])*R(1.0/6.0);
+    }
+    integrate_comp(E, v0, E.qvel_lo, q0, E.qpos_lo, acc, dv);
+#else
     DMC_UNROLL
     for (int i = 0; i < NV; i++) {
       dv[i] = (Fv[i] + 2*Fv[NV + i] + 2*Fv[2*NV + i] + Fv[3*NV + i])*R(1.0/6.0);
@@ -1667,6 +2082,7 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol) {
     DMC_UNROLL
     for (int i = 0; i < NQ; i++) E.qpos[i] = q0[i];
     integrate_pos(E.qpos, dv, h);
+#endif
     time = t0 + h;
   }
 }
@@ -1925,6 +2341,34 @@ DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
 // helpers above and supplies its own dmc_step / dmc_observe)
 // ---------------------------------------------------------------------------
 #ifndef DMC_COOP_BUILD
+// the workspace is laid out for the batch rounded up to whole workgroups
+DEV long long padded_envs(const DmcArgs& a) {
+  return ((long long)a.nenv + LANES - 1)/LANES*LANES;
+}
+// Surplus lanes of a partial last workgroup stay in the kernel (the solver
+// passes are executed by all lanes of the wavefront): they shadow the last env
+// with no constraint rows of their own and store nothing.
+struct LaneId { int e; long long slot; bool alive; };
+DEV LaneId lane_id(const DmcArgs& a) {
+  const long long raw = (long long)blockIdx.x*blockDim.x + threadIdx.x;
+  const bool alive = raw < a.nenv;
+  return LaneId{alive ? (int)raw : a.nenv - 1, raw, alive};
+}
+DEV Work make_work(const DmcArgs& a, real* lds, const LaneId& id) {
+  Work W;
+  const long long np = padded_envs(a);
+  W.lds0 = lds;
+  W.glb_rows = a.ws + (long long)blockIdx.x*GLB_ROWS*RW*LANES;
+  W.glb = a.ws + id.slot;
+  W.npad = np;
+  W.lane = threadIdx.x;
+  W.base = 0; W.cnt = 0; W.total = 0;
+  if (ROWPAR) {   // the per-env sums start from zero (and are left zero by `take`)
+    DMC_UNROLL
+    for (int k = 0; k < EB_NACC; k++) *W.eb(EB_ACC + k) = 0;
+  }
+  return W;
+}
 DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   const long long n = a.nenv;
   DMC_UNROLL
@@ -1932,6 +2376,23 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   DMC_UNROLL
   for (int i = 0; i < NV; i++) { E.qvel[i] = a.qvel[i*n + e]; E.warm[i] = a.warm[i*n + e]; }
   time = a.time[e];
+#ifdef DMC_STATE_COMP
+  {
+    const long long np = padded_envs(a);
+    const real* c = a.ws + (long long)WS_COMP*np + e;
+    DMC_UNROLL
+    for (int i = 0; i < NQ; i++) {
+      const real tag = c[i*np], lo = c[(NQ + i)*np];
+      E.qpos_lo[i] = tag == E.qpos[i] ? lo : R(0);
+    }
+    c += 2LL*NQ*np;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) {
+      const real tag = c[i*np], lo = c[(NV + i)*np];
+      E.qvel_lo[i] = tag == E.qvel[i] ? lo : R(0);
+    }
+  }
+#endif
   DMC_UNROLL
   for (int i = 0; i < NTASKDATA; i++) E.taskdata[i] = a.taskdata[sidx(i, e, n, NTDX)];
 #ifdef DMC_SOLVER_PROFILE
@@ -1948,6 +2409,17 @@ DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
   DMC_UNROLL
   for (int i = 0; i < NV; i++) { a.qvel[i*n + e] = E.qvel[i]; a.warm[i*n + e] = E.warm[i]; }
   a.time[e] = time;
+#ifdef DMC_STATE_COMP
+  {
+    const long long np = padded_envs(a);
+    real* c = a.ws + (long long)WS_COMP*np + e;
+    DMC_UNROLL
+    for (int i = 0; i < NQ; i++) { c[i*np] = E.qpos[i]; c[(NQ + i)*np] = E.qpos_lo[i]; }
+    c += 2LL*NQ*np;
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) { c[i*np] = E.qvel[i]; c[(NV + i)*np] = E.qvel_lo[i]; }
+  }
+#endif
   if (E.warn) a.warn[e] |= E.warn;
 }
 // The observation is handed over in the agent layout [env][NOBS].  One lane
@@ -1959,7 +2431,7 @@ DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
 constexpr bool OBS_STAGE_FITS = LDS_WORDS >= LANES*(NOBS > 0 ? NOBS : 1);
 
 DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
-                       real* lds_base) {
+                       real* lds_base, bool alive) {
   const long long n = a.nenv;
   real obs[NOBS > 0 ? NOBS : 1];
   const real rew = task_outputs(E, a, obs);
@@ -1972,10 +2444,11 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
     const long long left = n - base;
     const int nvalid = left < (long long)blockDim.x ? (int)left : (int)blockDim.x;
     real* out = a.obs + base*NOBS;
-    // lanes 0..nvalid-1 are exactly the active ones of a partial last block
-    for (int w = lane; w < nvalid*NOBS; w += nvalid)
+    for (int w = lane; w < nvalid*NOBS; w += LANES)
       out[w] = lds_base[(w % NOBS)*LANES + w/NOBS];
+    if (!alive) return;
   } else {
+    if (!alive) return;
     DMC_UNROLL
     for (int k = 0; k < NOBS; k++)
       a.obs[(long long)k*a.obs_sk + (long long)e*a.obs_se] = obs[k];
@@ -2016,8 +2489,8 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
 #endif
 extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_step(DmcArgs a) {
-  const int e = blockIdx.x*blockDim.x + threadIdx.x;
-  if (e >= a.nenv) return;
+  const LaneId id = lane_id(a);
+  const int e = id.e;
   Env E;
   real time;
   load_env(E, a, e, time);
@@ -2034,17 +2507,20 @@ dmc_step(DmcArgs a) {
       DMC_UNROLL
       for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
     }
-    DMC_UNROLL
-    for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
+    if (id.alive) {
+      DMC_UNROLL
+      for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
+    }
   } else {
     DMC_UNROLL
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
   __shared__ real lds_rows[LDS_WORDS];
-  Work W = {lds_rows + threadIdx.x, a.ws + e, n};
+  Work W = make_work(a, lds_rows, id);
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
-  for (int s = 0; s < a.nsub; s++) physics_step(E, W, time, tol);
-  if (a.qacc) {
+  for (int s = 0; s < a.nsub; s++)
+    physics_step(E, W, time, tol, id.alive, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
+  if (a.qacc && id.alive) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];
   }
@@ -2052,20 +2528,21 @@ dmc_step(DmcArgs a) {
 #ifndef DMC_ABLATE_OBS
     observe_stage(E, time);
 #endif
-    store_outputs(E, a, e, true, lds_rows);
+    store_outputs(E, a, e, true, lds_rows, id.alive);
   }
 #ifdef DMC_SOLVER_PROFILE
   __syncthreads();
-  for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
+  if (id.alive)
+    for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
 #endif
-  store_env(E, a, e, time);
+  if (id.alive) store_env(E, a, e, time);
 }
 
 // observation / reward / sensors of the current state (reset, after_reset)
 extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_observe(DmcArgs a) {
-  const int e = blockIdx.x*blockDim.x + threadIdx.x;
-  if (e >= a.nenv) return;
+  const LaneId id = lane_id(a);
+  const int e = id.e;
   Env E;
   real time;
   load_env(E, a, e, time);
@@ -2073,21 +2550,25 @@ dmc_observe(DmcArgs a) {
   DMC_UNROLL
   for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   __shared__ real lds_rows[LDS_WORDS];
-  if (NTOUCH > 0 && !(a.flags & 4)) {
+  Work W = make_work(a, lds_rows, id);
+  if (NTOUCH > 0) {
     // acceleration-stage sensors need the constraint forces: the reference's
-    // after_reset runs mj_forward with actuation disabled (engine.py:283-295)
-    Work W = {lds_rows + threadIdx.x, a.ws + e, n};
+    // after_reset runs mj_forward with actuation disabled (engine.py:283-295);
+    // a bad state is reset first (mj_checkPos), as mj_forward would see it
     const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
-    if (!check_state(E, time)) forward(E, W, false, tol);
+    check_state(E, time);
+    forward(E, W, false, tol, id.alive);
   }
+  const int ncon_forward = E.ncon, nefc_forward = E.nefc;
   observe_stage(E, time);
-  if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
-    Work W = {lds_rows + threadIdx.x, a.ws + e, n};
+  if (NTOUCH > 0) {
+    E.ncon = ncon_forward; E.nefc = nefc_forward;
+  } else if (a.flags & 4) {   // count contacts (humanoid reset rejection test)
     E.ncon = 0; E.nefc = 0;
     if (NPAIR > 0) detect_contacts(E, W);
   }
-  store_outputs(E, a, e, false, lds_rows);
-  store_env(E, a, e, time);
+  store_outputs(E, a, e, false, lds_rows, id.alive);
+  if (id.alive) store_env(E, a, e, time);
 }
 
 #endif  // !DMC_COOP_BUILD
@@ -2209,7 +2690,8 @@ dmc_init_episode(DmcArgs a) {
 extern "C" __device__ const int dmc_info[20] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     (WS_WORDS > 0 ? WS_WORDS : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
-    INTEGRATOR, NPAIR, LANES /*envs (= threads) per workgroup of dmc_step/dmc_observe*/,
+    INTEGRATOR, NPAIR, LANES /*envs (= threads) per workgroup of dmc_step/dmc_observe;
+                                the workspace is sized for the batch rounded up to this*/,
     DMC_ENV_MAJOR /*0: state fields are [k][env]*/, NTASKDATA,
     LANES /*threads per workgroup*/, 0, 0};
 #endif

@@ -33,15 +33,20 @@ def env_seeds(base_seed, total_envs, world_size, rank):
   return np.arange(start, stop, dtype=np.int64) + int(base_seed)
 
 
-def init_process_group(backend=None):
-  """Initialises torch.distributed from the torchrun environment."""
+def init_process_group(backend=None, single_rank_group=False):
+  """Initialises torch.distributed from the torchrun environment.
+
+  A world of one needs no process group; `single_rank_group=True` creates it
+  anyway (bench.py under a one-rank torchrun, so that the RCCL path is
+  exercised on a single-GPU box too).
+  """
   import torch
   import torch.distributed as dist
   if dist.is_initialized():
     return dist.get_rank(), dist.get_world_size()
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
-  if world == 1:
+  if world == 1 and not single_rank_group:
     return 0, 1
   os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
   os.environ.setdefault('MASTER_PORT', '29500')

@@ -396,6 +396,7 @@ class Physics(_control.Physics):
     path = build.build_model(
         model, self._task_id, precision, ncon_max, mode=self._build_mode,
         lds_budget=build.lds_budget_for(self._batch_size), group=self._group)
+    self._code_object = path
     self._hip_model = wrapper.HipModel(path, device)
     self._batch = wrapper.HipBatch(self._hip_model, self._batch_size)
     self.data = _Data(self)
@@ -429,6 +430,18 @@ class Physics(_control.Physics):
   def dtype(self):
     return self._hip_model.dtype
 
+  @property
+  def code_object(self):
+    """Path of the gfx950 code object this batch runs (content-hashed name)."""
+    return self._code_object
+
+  @property
+  def kernel_shape(self):
+    info = self._hip_model.info
+    if info.lanes_per_env > 1:
+      return '%d lanes per env (csrc/dmc_coop.hip)' % info.lanes_per_env
+    return 'one env per lane (csrc/dmc_kernels.hip)'
+
   # -- stepping -----------------------------------------------------------------
   @contextlib.contextmanager
   def suppress_physics_errors(self):
@@ -457,15 +470,22 @@ class Physics(_control.Physics):
     """Zero-copy control: a device address plus element strides (in reals)."""
     self._pending_ctrl = ('device', int(ptr), int(stride_k), int(stride_env))
 
-  def step(self, n_sub_steps=1, outputs=True, check=True):
-    """`n_sub_steps` x (mj_step2|mj_step + mj_step1), one kernel launch."""
+  def step(self, n_sub_steps=1, outputs=True, check=True, stale_first=False):
+    """`n_sub_steps` x (mj_step2|mj_step + mj_step1), one kernel launch.
+
+    stale_first: the first substep is an `mj_step2` on the position/velocity
+    stage left by `reset()` (qpos0), applied to the current state -- the order
+    of operations of a task that rewrites qpos inside `reset_context` and steps
+    without a forward pass (suite/cheetah.py:63-77)."""
     ctrl = self._pending_ctrl
     if self._profiling:
       self._batch.timer_start()
     if isinstance(ctrl, tuple):
+      if stale_first:
+        raise ValueError('stale_first applies to settle steps (no new control)')
       self._batch.step_device(ctrl[1], ctrl[2], ctrl[3], n_sub_steps, outputs)
     else:
-      self._batch.step_host(ctrl, n_sub_steps, outputs)
+      self._batch.step_host(ctrl, n_sub_steps, outputs, stale_first)
     if self._profiling:
       ms, _ = self._batch.timer_stop()
       self._profile_seconds += ms*1e-3

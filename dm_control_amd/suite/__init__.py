@@ -1,80 +1,98 @@
 """Control Suite loader for the batched MI355X physics step.
 
-Same contract as /root/reference/dm_control/suite/__init__.py:78-150:
+Contract of the reference's loader
+(/root/reference/dm_control/suite/__init__.py:78-150, loader_test.py:23-42):
 `load(domain_name, task_name, task_kwargs, environment_kwargs,
 visualize_reward)` returns a `control.Environment`; unknown names raise
-ValueError; the tag-derived constants exist.  Domains currently built on the
-HIP path: cartpole, cheetah, humanoid plus walker, pendulum,
-acrobot, hopper, reacher and point_mass (first SURVEY.md 8f row); the remaining reference
-domains need primitives that are not implemented yet.
+ValueError; the tag-derived task tuples exist under the same names.
+
+Domains on the HIP path: cartpole, cheetah, humanoid and walker,
+pendulum, acrobot, hopper, reacher, point_mass.  The other
+reference domains need physics that is not built.
 
 Batched use: `environment_kwargs={'batch_size': 8192, 'device': 0,
 'precision': 'f32', 'device_init': True}`.
 """
 
-import collections
-import inspect
+import importlib
 
 from dm_control_amd.rl import control
-from dm_control_amd.suite import acrobot
-from dm_control_amd.suite import cartpole
-from dm_control_amd.suite import cheetah
-from dm_control_amd.suite import hopper
-from dm_control_amd.suite import humanoid
-from dm_control_amd.suite import pendulum
-from dm_control_amd.suite import point_mass
-from dm_control_amd.suite import reacher
-from dm_control_amd.suite import walker
 
-_DOMAINS = {name: module for name, module in locals().items()
-            if inspect.ismodule(module) and hasattr(module, 'SUITE')}
+# The registry is an explicit table: one row per domain module on the HIP path.
+DOMAIN_NAMES = ('acrobot', 'cartpole', 'cheetah', 'hopper', 'humanoid',
+                'pendulum', 'point_mass', 'reacher', 'walker')
 
 
-def _get_tasks(tag):
-  result = []
-  for domain_name in sorted(_DOMAINS.keys()):
-    domain = _DOMAINS[domain_name]
-    tasks = domain.SUITE if tag is None else domain.SUITE.tagged(tag)
-    for task_name in tasks.keys():
-      result.append((domain_name, task_name))
-  return tuple(result)
+class _Registry:
+  """domain name -> module, with the task tables derived once at import."""
+
+  def __init__(self, names):
+    self.modules = {}
+    for name in names:
+      module = importlib.import_module('dm_control_amd.suite.' + name)
+      if not hasattr(module, 'SUITE'):
+        raise ImportError('suite domain %r defines no SUITE task table' % name)
+      self.modules[name] = module
+      globals()[name] = module        # `suite.cheetah` etc. stay importable
+
+  def pairs(self, tag=None):
+    """(domain, task) pairs in domain-then-registration order."""
+    out = []
+    for name in sorted(self.modules):
+      table = self.modules[name].SUITE
+      chosen = table if tag is None else table.tagged(tag)
+      out.extend((name, task) for task in chosen)
+    return tuple(out)
+
+  def factory(self, domain_name, task_name):
+    module = self.modules.get(domain_name)
+    if module is None:
+      raise ValueError('Domain {!r} does not exist.'.format(domain_name))
+    if task_name not in module.SUITE:
+      raise ValueError('Level {!r} does not exist in domain {!r}.'.format(
+          task_name, domain_name))
+    return module.SUITE[task_name]
 
 
-def _get_tasks_by_domain(tasks):
-  result = collections.defaultdict(list)
-  for domain_name, task_name in tasks:
-    result[domain_name].append(task_name)
-  return {k: tuple(v) for k, v in result.items()}
+_REGISTRY = _Registry(DOMAIN_NAMES)
+_DOMAINS = _REGISTRY.modules
 
 
-ALL_TASKS = _get_tasks(tag=None)
-BENCHMARKING = _get_tasks('benchmarking')
-EASY = _get_tasks('easy')
-HARD = _get_tasks('hard')
-EXTRA = tuple(sorted(set(ALL_TASKS) - set(BENCHMARKING)))
-NO_REWARD_VIZ = _get_tasks('no_reward_visualization')
-REWARD_VIZ = tuple(sorted(set(ALL_TASKS) - set(NO_REWARD_VIZ)))
-TASKS_BY_DOMAIN = _get_tasks_by_domain(ALL_TASKS)
+def _without(pairs, excluded):
+  drop = set(excluded)
+  return tuple(sorted(p for p in pairs if p not in drop))
 
 
-def load(domain_name, task_name, task_kwargs=None, environment_kwargs=None,
-         visualize_reward=False):
-  """Returns an environment from a domain name, task name and settings."""
-  return build_environment(domain_name, task_name, task_kwargs,
-                           environment_kwargs, visualize_reward)
+ALL_TASKS = _REGISTRY.pairs()
+BENCHMARKING = _REGISTRY.pairs('benchmarking')
+EASY = _REGISTRY.pairs('easy')
+HARD = _REGISTRY.pairs('hard')
+NO_REWARD_VIZ = _REGISTRY.pairs('no_reward_visualization')
+EXTRA = _without(ALL_TASKS, BENCHMARKING)
+REWARD_VIZ = _without(ALL_TASKS, NO_REWARD_VIZ)
+TASKS_BY_DOMAIN = {
+    domain: tuple(task for d, task in ALL_TASKS if d == domain)
+    for domain in sorted(_DOMAINS)}
 
 
 def build_environment(domain_name, task_name, task_kwargs=None,
                       environment_kwargs=None, visualize_reward=False):
-  if domain_name not in _DOMAINS:
-    raise ValueError('Domain {!r} does not exist.'.format(domain_name))
-  domain = _DOMAINS[domain_name]
-  if task_name not in domain.SUITE:
-    raise ValueError('Level {!r} does not exist in domain {!r}.'.format(
-        task_name, domain_name))
-  task_kwargs = task_kwargs or {}
+  """Looks the task factory up and calls it (suite/__init__.py:117-150)."""
+  factory = _REGISTRY.factory(domain_name, task_name)
+  kwargs = dict(task_kwargs or {})
   if environment_kwargs is not None:
-    task_kwargs = dict(task_kwargs, environment_kwargs=environment_kwargs)
-  env = domain.SUITE[task_name](**task_kwargs)
+    kwargs['environment_kwargs'] = environment_kwargs
+  env = factory(**kwargs)
+  if not isinstance(env, control.Environment):
+    raise TypeError('task factory {}.{} returned {!r}'.format(
+        domain_name, task_name, type(env)))
   env.task.visualize_reward = visualize_reward
   return env
+
+
+def load(domain_name, task_name, task_kwargs=None, environment_kwargs=None,
+         visualize_reward=False):
+  """`suite.load` of the reference (suite/__init__.py:93-114)."""
+  return build_environment(domain_name, task_name, task_kwargs=task_kwargs,
+                           environment_kwargs=environment_kwargs,
+                           visualize_reward=visualize_reward)

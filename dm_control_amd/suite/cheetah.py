@@ -59,8 +59,11 @@ class Cheetah(base.Task):
       qpos = np.array(rows)
       physics.data.qpos[:] = qpos[0] if physics.batch_size is None else qpos
     # Stabilize the model before the actual simulation: 200 physics steps in
-    # one launch, no observation/reward work (cheetah.py:72-73).
-    physics.step(_SETTLE_STEPS, outputs=False)
+    # one launch, no observation/reward work (cheetah.py:72-73).  The reference
+    # takes them right after overwriting qpos, without a forward pass, so its
+    # first mj_step2 still works on the mass matrix, bias and contacts that
+    # reset_context computed at qpos0: `stale_first`.
+    physics.step(_SETTLE_STEPS, outputs=False, stale_first=True)
     physics.data.time = 0
     super().initialize_episode(physics)
 

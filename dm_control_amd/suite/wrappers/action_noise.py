@@ -4,10 +4,6 @@ import numpy as np
 
 from dm_control_amd import _dm_env as dm_env
 
-_BOUNDS_MUST_BE_FINITE = (
-    'All bounds in `env.action_spec()` must be finite, got: {action_spec}')
-
-
 class Wrapper(dm_env.Environment):
   """Noise std = `scale` x (max - min) per action dimension, then clipped.
 
@@ -16,14 +12,15 @@ class Wrapper(dm_env.Environment):
   """
 
   def __init__(self, env, scale=0.01):
-    action_spec = env.action_spec()
-    if not (np.all(np.isfinite(action_spec.minimum)) and
-            np.all(np.isfinite(action_spec.maximum))):
-      raise ValueError(_BOUNDS_MUST_BE_FINITE.format(action_spec=action_spec))
-    self._minimum = action_spec.minimum
-    self._maximum = action_spec.maximum
-    self._noise_std = scale*(action_spec.maximum - action_spec.minimum)
+    spec = env.action_spec()
+    lo = np.asarray(spec.minimum, dtype=np.float64)
+    hi = np.asarray(spec.maximum, dtype=np.float64)
+    if not np.isfinite(np.concatenate([lo.ravel(), hi.ravel()])).all():
+      raise ValueError('action noise is scaled by the action range, which must '
+                       'be finite; got minimum={}, maximum={}'.format(lo, hi))
     self._env = env
+    self._minimum, self._maximum = lo, hi
+    self._noise_std = float(scale)*(hi - lo)
 
   def step(self, action):
     action = np.asarray(action, dtype=np.float64)

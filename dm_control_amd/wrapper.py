@@ -225,11 +225,15 @@ class HipBatch:
   def forward(self, count_contacts=False):
     _check(self._lib.dmc_batch_forward(self.ptr, int(count_contacts)))
 
-  def step_host(self, ctrl, nsub=1, want_outputs=True):
-    """ctrl: host array [nenv, nu] (agent layout) or None."""
+  def step_host(self, ctrl, nsub=1, want_outputs=True, stale_first=False):
+    """ctrl: host array [nenv, nu] (agent layout) or None.
+
+    stale_first: DMC_STEP_STALE_FIRST (the first substep takes its acceleration
+    from the reset state; the reference cheetah's first settle step)."""
+    want_outputs = int(bool(want_outputs)) | (2 if stale_first else 0)
     if ctrl is None:
       _check(self._lib.dmc_batch_step(self.ptr, None, 0, 0, 0, nsub,
-                                      int(want_outputs)))
+                                      want_outputs))
       return
     c = np.ascontiguousarray(ctrl, dtype=self.model.dtype)
     nu = self.model.info.nu

@@ -127,11 +127,21 @@ int dmc_batch_init_episode(dmc_batch* batch, uint64_t seed, int only_colliding);
  * narrowphase so DMC_FIELD_STATS[0] = ncon) */
 int dmc_batch_forward(dmc_batch* batch, int count_contacts);
 
+/* bits of the `want_outputs` argument of dmc_batch_step / dmc_batch_step_n */
+#define DMC_STEP_OUTPUTS 1       /* compute observation/reward after the last substep
+                                  * (0: settle steps, task.initialize_episode) */
+#define DMC_STEP_STALE_FIRST 2   /* the FIRST substep takes its acceleration from the
+                                  * position/velocity stage of the reset state (qpos0,
+                                  * zero velocity): what mj_step2 sees when a task
+                                  * rewrites qpos after reset_context's mj_forward and
+                                  * steps without a forward pass
+                                  * (suite/cheetah.py:63-77, engine.py:149-166) */
+
 /* nsub x Physics.step, then observation + reward.
  * ctrl: element (k, env) at ctrl[k*stride_k + env*stride_env] (in reals);
  * host pointer when on_device == 0 (copied), device pointer otherwise
  * (zero-copy, e.g. a torch tensor).  ctrl == NULL keeps the previous control.
- * want_outputs == 0 skips observation/reward (settle steps). */
+ * want_outputs: DMC_STEP_* bits (0 skips observation/reward). */
 int dmc_batch_step(dmc_batch* batch, const void* ctrl, long long stride_k,
                    long long stride_env, int on_device, int nsub,
                    int want_outputs);
