@@ -365,18 +365,30 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   tr('pair_solimp', pair_solimp); tr('pair_diag', pair_diag)
   ti('task_body', (task_bodies(m, task) + [0]*6)[:6])
   sites = task_sites(m, task)
-  # touch sensors: spherical zone around a site (mj_sensorAcc, mjSENS_TOUCH)
+  # touch sensors: the zone is the sensor's site, a sphere or a box
+  # (mj_sensorAcc, mjSENS_TOUCH; wrapper/core_test.py:329-344 uses a box site)
   touch = [i for i in range(m.nsensor) if int(m.sensor_type[i]) == SENS_TOUCH]
+  touch_type, touch_size, touch_mat = [], [], []
   for i in touch:
     sid = int(m.sensor_objid[i])
-    if getattr(m, 'site_type', None) is not None and int(m.site_type[sid]) != mdl.GEOM_SPHERE:
-      raise UnsupportedModelError('touch sensors need a spherical site')
+    kind = (int(m.site_type[sid]) if getattr(m, 'site_type', None) is not None
+            else mdl.GEOM_SPHERE)
+    if kind not in (mdl.GEOM_SPHERE, mdl.GEOM_BOX):
+      raise UnsupportedModelError('touch sensors need a spherical or box site')
+    touch_type.append(kind)
+    touch_size += [float(v) for v in m.site_size[sid]]
+    w, x, y, z = [float(v) for v in m.site_quat[sid]]
+    touch_mat += [w*w + x*x - y*y - z*z, 2*(x*y - w*z), 2*(x*z + w*y),
+                  2*(x*y + w*z), w*w - x*x + y*y - z*z, 2*(y*z - w*x),
+                  2*(x*z - w*y), 2*(y*z + w*x), w*w - x*x - y*y + z*z]
   ci('NTOUCH', len(touch))
   ti('touch_adr', [int(m.sensor_adr[i]) for i in touch])
   ti('touch_body', [int(m.site_bodyid[int(m.sensor_objid[i])]) for i in touch])
+  ti('touch_type', touch_type)
   tr('touch_pos', [float(v) for i in touch
                    for v in m.site_pos[int(m.sensor_objid[i])]] or [0, 0, 0])
-  tr('touch_radius', [float(m.site_size[int(m.sensor_objid[i])][0]) for i in touch])
+  tr('touch_size', touch_size or [0, 0, 0])      # sphere: radius first
+  tr('touch_mat', touch_mat or [1, 0, 0, 0, 1, 0, 0, 0, 1])   # site frame in its body
   ti('task_site_body', [s[0] for s in sites] or [0])
   tr('task_site_pos', [v for s in sites for v in s[1]] or [0, 0, 0])
   tr('task_site_size', [s[2] for s in sites] or [0])

@@ -347,9 +347,12 @@ int dmc_batch_set_state(dmc_batch* b, const void* qpos, const void* qvel,
 
 int dmc_batch_write(dmc_batch* b, int field, const void* src, size_t bytes) {
   if (!b || !src) return fail("dmc_batch_write: null argument");
+  // the integration state, the per-instance task data and what a checkpoint
+  // must restore besides (last applied control, episode return, warning mask)
   if (field != DMC_FIELD_QPOS && field != DMC_FIELD_QVEL &&
       field != DMC_FIELD_WARMSTART && field != DMC_FIELD_TIME &&
-      field != DMC_FIELD_TASKDATA)
+      field != DMC_FIELD_TASKDATA && field != DMC_FIELD_CTRL &&
+      field != DMC_FIELD_RETURN && field != DMC_FIELD_WARN)
     return fail("dmc_batch_write: field %d is not writable", field);
   if (bytes != b->bytes[field])
     return fail("dmc_batch_write: field %d has %zu bytes, caller passed %zu",

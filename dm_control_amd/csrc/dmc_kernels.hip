@@ -318,22 +318,12 @@ struct Env {
   unsigned warn;
 };
 
-// Constraint rows: record = [J(0..NV-1), D, aref, Jaref, Jv (, owner env)].
-// Records are stored in "rounds" of LANES slots, [round][word][slot]; the first
-// LDS_ROWS rounds live in LDS, the rest in the HBM workspace of the workgroup.
-//
-// Row-parallel solver (ROWPAR, the default whenever its per-env exchange buffer
-// fits): the rows of the whole workgroup are packed densely -- env e owns the
-// slots base[e] .. base[e] + nefc[e] - 1, base = exclusive prefix sum of the
-// row counts -- so that in the solver passes lane l of round k handles slot
-// 64 k + l whatever env it belongs to: a pass costs (total rows)/64 rounds
-// instead of max_e nefc[e] rounds, and slot addresses are lane-contiguous
-// (conflict-free LDS access).  Per-env sums (Hessian, forces, line-search
-// terms) are reduced with LDS float atomics into the exchange buffer.
-// Otherwise (very large NV) env e keeps its row r in slot e of round r and every
-// lane walks its own rows (the round count is then the per-env row count).
-// Contact records ([pos3 n3 tangent-hint3 dist pair]) are per-lane in both
-// modes: record k of every lane in one [word][lane] block.
+// Constraint rows: record r = [J(0..NV-1), D, aref, Jaref, Jv].  The first
+// LDS_ROWS records of each lane live in LDS ([record word][lane]: every lane
+// hits its own bank, conflict-free for any per-lane row index); records beyond
+// that spill to the HBM workspace with the same [word][env] layout.
+// Contact records ([pos3 n3 tangent-hint3 dist pair]) use the same two tiers.
+constexpr int RW = NV + 4;
 constexpr int CW = 11;
 #ifndef DMC_LDS_BUDGET
 #define DMC_LDS_BUDGET (128*1024)
@@ -341,27 +331,8 @@ constexpr int CW = 11;
 #ifndef DMC_CON_LDS
 #define DMC_CON_LDS 12
 #endif
-#ifndef DMC_ROWPAR
-#define DMC_ROWPAR 1
-#endif
 constexpr int REC_BYTES = LANES*(int)sizeof(real);    // one record word, all lanes
-// exchange buffer of the row-parallel solver, [word][env]:
-//   EB_VEC (NV)  per-env vector the row lanes read (warm start / search direction)
-//   EB_ALPHA, EB_ACTIVE   step to apply / env still iterating
-//   EB_ACC (NM + NV + 1)  per-env sums: Hessian terms, constraint force, number
-//                         of active-set changes (the warm-start and line-search
-//                         passes use the first few; the warm-start pass also
-//                         parks qacc_smooth in words 2 .. 2 + NV)
-constexpr int EB_VEC = 0, EB_ALPHA = NV, EB_ACTIVE = NV + 1, EB_ACC = NV + 2;
-constexpr int EB_NACC = NM + NV + 1;
-constexpr int EB_WORDS_ = EB_ACC + EB_NACC;
-// (needs room for the buffer plus at least two row rounds and two contacts)
-constexpr bool ROWPAR = DMC_ROWPAR != 0 && NV > 0 && NEFC_MAX > 0 &&
-                        (EB_WORDS_ + 2*(NV + 5) + 2*CW)*REC_BYTES <= DMC_LDS_BUDGET;
-constexpr int EB_WORDS = ROWPAR ? EB_WORDS_ : 0;
-constexpr int RW = NV + 4 + (ROWPAR ? 1 : 0);
-enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3, ROW_ENV = NV + 4 };
-constexpr int REC_BUDGET = DMC_LDS_BUDGET - EB_WORDS*REC_BYTES;
+constexpr int REC_BUDGET = DMC_LDS_BUDGET;
 constexpr int LDS_CONS_WANT = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
 constexpr int LDS_CONS_FIT = (REC_BUDGET/2)/(CW*REC_BYTES);   // <= half the budget
 constexpr int LDS_CONS = LDS_CONS_WANT < LDS_CONS_FIT ? LDS_CONS_WANT : LDS_CONS_FIT;
@@ -370,33 +341,25 @@ constexpr int LDS_ROWS = LDS_ROWS_FIT < NEFC_MAX ? LDS_ROWS_FIT : NEFC_MAX;
 static_assert(LDS_CONS >= 0 && LDS_ROWS >= 0, "LDS budget arithmetic");
 constexpr int GLB_ROWS = NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 0;
 constexpr int GLB_CONS = NCON_MAX - LDS_CONS > 0 ? NCON_MAX - LDS_CONS : 0;
+enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3 };
 
 struct LdsRow {
   real* p;
   __device__ __forceinline__ real get(int k) const { return p[k*LANES]; }
   __device__ __forceinline__ void set(int k, real v) const { p[k*LANES] = v; }
 };
-struct GlbRow {   // overflow rows: [round][word][slot], per workgroup
-  real* p;
-  __device__ __forceinline__ real get(int k) const { return p[k*LANES]; }
-  __device__ __forceinline__ void set(int k, real v) const { p[k*LANES] = v; }
-};
-struct GlbCon {   // overflow contacts: [word][env]
+struct GlbRow {
   real* p; long long n;
   __device__ __forceinline__ real get(int k) const { return p[k*n]; }
   __device__ __forceinline__ void set(int k, real v) const { p[k*n] = v; }
 };
-// workspace words per env: overflow rows (the workgroup's block of
-// GLB_ROWS*RW*LANES words, i.e. GLB_ROWS*RW per env), overflow contacts, then
-// (-DDMC_STATE_COMP) the low words of the fp64 state:
-// qpos/qvel are then carried between steps as fp64 values split into the public
-// fp32 field (high word) and a low word kept here together with the high word
-// it belongs to (a field overwritten from outside -- set_state, reset -- no
-// longer matches its tag and the low word is dropped).
-// The host allocates ws_per_env words for the batch size rounded up to whole
-// workgroups.
-constexpr int WS_CONS = GLB_ROWS*RW;
-constexpr int WS_COMP = WS_CONS + GLB_CONS*CW;
+// workspace words per env: overflow rows, overflow contacts, then
+// (-DDMC_STATE_COMP) the low words of the fp64 state: qpos/qvel are then
+// carried between steps as fp64 values split into the public fp32 field (high
+// word) and a low word kept here together with the high word it belongs to (a
+// field overwritten from outside -- set_state, reset -- no longer matches its
+// tag and the low word is dropped)
+constexpr int WS_COMP = GLB_ROWS*RW + GLB_CONS*CW;
 #ifdef DMC_STATE_COMP
 constexpr int WS_WORDS = WS_COMP + 2*(NQ + NV);
 #else
@@ -404,61 +367,47 @@ constexpr int WS_WORDS = WS_COMP;
 #endif
 
 struct Work {
-  real* lds0;     // LDS base of the workgroup: row rounds, contacts, exchange buffer
-  real* glb_rows; // overflow row rounds of this workgroup
-  real* glb;      // per-env workspace base + env ([idx][npad] layout)
-  long long npad; // envs rounded up to whole workgroups (stride of `glb`)
-  int lane;
-  int base;       // ROWPAR: first slot of this lane's env; else unused
-  int cnt;        // ROWPAR: number of rows this env will build
-  int total;      // ROWPAR: rows of the whole workgroup (wave-uniform)
-  // slot s of the row store
-  __device__ __forceinline__ bool in_lds(int s) const {
-    return LDS_ROWS >= NEFC_MAX || (s >> 6) < LDS_ROWS;
-  }
-  __device__ __forceinline__ LdsRow lslot(int s) const {
-    return LdsRow{lds0 + (s >> 6)*RW*LANES + (s & 63)};
-  }
-  __device__ __forceinline__ GlbRow gslot(int s) const {
-    return GlbRow{glb_rows + ((s >> 6) - LDS_ROWS)*RW*LANES + (s & 63)};
-  }
-  // slot of row r of this lane's env
-  __device__ __forceinline__ int slot(int r) const {
-    return ROWPAR ? base + r : r*LANES + lane;
+  real* lds;   // LDS base + lane (rows, then contact records)
+  real* glb;   // workspace base + env
+  long long nenv;
+  __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*LANES}; }
+  __device__ __forceinline__ GlbRow grow(int r) const {
+    return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
   }
   __device__ __forceinline__ LdsRow lcon(int k) const {
-    return LdsRow{lds0 + (LDS_ROWS*RW + k*CW)*LANES + lane};
+    return LdsRow{lds + (LDS_ROWS*RW + k*CW)*LANES};
   }
-  __device__ __forceinline__ GlbCon gcon(int k) const {
-    return GlbCon{glb + ((long long)WS_CONS + (long long)(k - LDS_CONS)*CW)*npad, npad};
-  }
-  __device__ __forceinline__ real* eb(int word) const {   // exchange buffer, this lane's env
-    return lds0 + (LDS_ROWS*RW + LDS_CONS*CW + word)*LANES + lane;
-  }
-  __device__ __forceinline__ real* eb_of(int word, int env) const {
-    return lds0 + (LDS_ROWS*RW + LDS_CONS*CW + word)*LANES + env;
+  __device__ __forceinline__ GlbRow gcon(int k) const {
+    return GlbRow{glb + ((long long)GLB_ROWS*RW + (long long)(k - LDS_CONS)*CW)*nenv, nenv};
   }
 };
-constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW + EB_WORDS > 0
-                           ? LDS_ROWS*RW + LDS_CONS*CW + EB_WORDS : 1)*LANES;
-// f(row handle) for this lane's rows [0, nefc)
+constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW > 0 ? LDS_ROWS*RW + LDS_CONS*CW : 1)*LANES;
+// f(row handle) for rows [0, nefc): LDS tier first, then the HBM tier
 template <class F>
 static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) {
-  for (int r = 0; r < nefc; r++) {
-    const int s = W.slot(r);
-    if (W.in_lds(s)) f(W.lslot(s)); else f(W.gslot(s));
-  }
+  const int n1 = nefc < LDS_ROWS ? nefc : LDS_ROWS;
+  for (int r = 0; r < n1; r++) f(W.lrow(r));
+  if (LDS_ROWS < NEFC_MAX)
+    for (int r = LDS_ROWS; r < nefc; r++) f(W.grow(r));
 }
-// f(row handle) for every slot of the workgroup, one slot per lane and round
-// (ROWPAR; `total` is wave-uniform, so the tier test is a scalar branch)
-template <class F>
-static __device__ __forceinline__ void for_slots(const Work& W, F&& f) {
-  const int rounds = (W.total + LANES - 1)/LANES;
-  for (int k = 0; k < rounds; k++) {
-    const int s = k*LANES + W.lane;
-    if (LDS_ROWS >= NEFC_MAX || k < LDS_ROWS) { if (s < W.total) f(W.lslot(s)); }
-    else { if (s < W.total) f(W.gslot(s)); }
+// The same in two stages: `load(row handle)` returns the words a row needs,
+// `use(words)` consumes them; the words of row r + 1 are requested before row r
+// is consumed, so that a lone wave overlaps the LDS round trip of the cheap
+// passes (line search: 3 words and a dozen instructions per row) with work.
+template <class L, class U>
+static __device__ __forceinline__ void for_rows_ahead(const Work& W, int nefc, L&& load, U&& use) {
+  const int n1 = nefc < LDS_ROWS ? nefc : LDS_ROWS;
+  if (n1 > 0) {
+    auto cur = load(W.lrow(0));
+    for (int r = 1; r < n1; r++) {
+      const auto nxt = load(W.lrow(r));
+      use(cur);
+      cur = nxt;
+    }
+    use(cur);
   }
+  if (LDS_ROWS < NEFC_MAX)
+    for (int r = LDS_ROWS; r < nefc; r++) use(load(W.grow(r)));
 }
 
 struct Mats {
@@ -886,34 +835,13 @@ DEV void write_row(const Row& rec, const Env& E, const real* row, real pm,
 }
 DEV bool push_row(Env& E, const Work& W, const real* row, real pos_minus_margin,
                   real K, real B, real imp, real Rrow) {
-  // ROWPAR: W.cnt (count_rows) is what this env reserved in the packed store
-  if (E.nefc >= (ROWPAR ? W.cnt : NEFC_MAX)) { E.warn |= WARN_CNSTRFULL; return false; }
-  const int s = W.slot(E.nefc++);
-  if (W.in_lds(s)) {
-    const LdsRow rec = W.lslot(s);
-    write_row(rec, E, row, pos_minus_margin, K, B, imp, Rrow);
-    if (ROWPAR) rec.set(ROW_ENV, (real)W.lane);
-  } else {
-    const GlbRow rec = W.gslot(s);
-    write_row(rec, E, row, pos_minus_margin, K, B, imp, Rrow);
-    if (ROWPAR) rec.set(ROW_ENV, (real)W.lane);
-  }
+  if (E.nefc >= NEFC_MAX) { E.warn |= WARN_CNSTRFULL; return false; }
+  const int r = E.nefc++;
+  if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS)
+    write_row(W.lrow(r), E, row, pos_minus_margin, K, B, imp, Rrow);
+  else
+    write_row(W.grow(r), E, row, pos_minus_margin, K, B, imp, Rrow);
   return true;
-}
-
-// rows limit_rows() will build (ROWPAR reserves slots before building)
-DEV int count_limit_rows(const Env& E) {
-  if (DISABLEFLAGS & (DSBL_LIMIT | DSBL_CONSTRAINT)) return 0;
-  int n = 0;
-  DMC_UNROLL
-  for (int l = 0; l < NLIMIT; l++) {
-    const int j = limit_jnt[l], qa = jnt_qposadr[j];
-    const real margin = R(jnt_margin[j]);
-    const real q = E.qpos[qa];
-    n += (q - R(jnt_range[2*j]) < margin) ? 1 : 0;
-    n += (R(jnt_range[2*j + 1]) - q < margin) ? 1 : 0;
-  }
-  return n;
 }
 
 DEV void limit_rows(Env& E, const Work& W) {
@@ -1266,22 +1194,8 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
   }
 }
 
-// rows contact_rows() will build from the contact list
-template <class Rec>
-DEV int rows_of_contact_count(const Rec& rec) {
-  const int p = (int)rec.get(10);
-  return rec.get(9) < pair_includemargin[p] ? pair_nrow[p] : 0;
-}
-DEV int count_contact_rows(const Env& E, const Work& W) {
-  int n = 0;
-  const int n1 = E.ncon < LDS_CONS ? E.ncon : LDS_CONS;
-  for (int k = 0; k < n1; k++) n += rows_of_contact_count(W.lcon(k));
-  if (LDS_CONS < NCON_MAX)
-    for (int k = LDS_CONS; k < E.ncon; k++) n += rows_of_contact_count(W.gcon(k));
-  return n;
-}
-
 DEV void contact_rows(Env& E, const Work& W) {
+  detect_contacts(E, W);
   const int n1 = E.ncon < LDS_CONS ? E.ncon : LDS_CONS;
   for (int k = 0; k < n1; k++) rows_of_contact(E, W, W.lcon(k));
   if (LDS_CONS < NCON_MAX)
@@ -1292,18 +1206,20 @@ DEV void contact_rows(Env& E, const Work& W) {
 // Newton solver on the primal problem (mj_fwdConstraint)
 // ---------------------------------------------------------------------------
 struct LsPoint { real alpha, dcost, d0, d1; };
+struct LsWords { real x0, v, D; };
 
 // cost relative to alpha = 0 (no cancellation), first and second derivative
 DEV void ls_eval(LsPoint& P, real alpha, const Env& E, const Work& W, real q1, real q2) {
   real dcost = alpha*alpha*q2 + alpha*q1;
   real d0 = 2*alpha*q2 + q1, d1 = 2*q2;
-  for_rows(W, E.nefc, [&](auto rec) {
-    const real x0 = rec.get(ROW_JAR), v = rec.get(ROW_JV), D = rec.get(ROW_D);
-    const real x = x0 + alpha*v;
-    const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
-    dcost += R(0.5)*D*(a*a - a0*a0);
-    if (x < 0) { d0 += D*x*v; d1 += D*v*v; }
-  });
+  for_rows_ahead(W, E.nefc,
+      [&](auto rec) { return LsWords{rec.get(ROW_JAR), rec.get(ROW_JV), rec.get(ROW_D)}; },
+      [&](const LsWords& w) {
+        const real x = w.x0 + alpha*w.v;
+        const real a = x < 0 ? x : R(0), a0 = w.x0 < 0 ? w.x0 : R(0);
+        dcost += R(0.5)*w.D*(a*a - a0*a0);
+        if (x < 0) { d0 += w.D*x*w.v; d1 += w.D*w.v*w.v; }
+      });
   P.alpha = alpha; P.dcost = dcost; P.d0 = d0;
   P.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
 }
@@ -1312,30 +1228,43 @@ DEV void ls_eval(LsPoint& P, real alpha, const Env& E, const Work& W, real q1, r
 // summed per lane, returned through Env::prof and written over the observation
 #ifdef DMC_SOLVER_PROFILE
 #define SPROF(k) do { const long long t_ = wall_clock64(); E.prof[k] += (real)(t_ - tl_); tl_ = t_; } while (0)
+#define SCOUNT(k) do { E.prof[k] += 1; } while (0)
 #else
 #define SPROF(k) do {} while (0)
+#define SCOUNT(k) do {} while (0)
 #endif
-DEV void solve_newton(Env& E, const Work& W, real tol) {
+// A wave runs every pass over the rows as long as its busiest lane needs, and
+// a lone wave cannot hide the LDS round trip of a row, so the solver is built
+// around few, fused passes:
+//   (A) applies the previous step to Jaref, notes active-set changes and
+//       accumulates the constraint force; the Hessian M + J^T D_active J is
+//       kept across iterations and only the rows that changed sides are added
+//       or removed (most iterations: none), instead of rebuilding 45 products
+//       per row and iteration;
+//   (B) computes Jv and the line-search derivatives at alpha = 0 and, in the
+//       fp32 build, already evaluates alpha = 1 -- the exact Newton step, which
+//       is what -d0/d1 evaluates to when the active set does not change -- so
+//       the usual iteration needs no separate line-search pass.
+// `start_smooth`: Jaref of the start point is the candidate parked in ROW_JV
+// (the warm start lost against qacc_smooth); folded into the first pass A.
+DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
 #ifdef DMC_SOLVER_PROFILE
   long long tl_ = wall_clock64();
 #endif
   real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], Hreg[MAT_REGS];
   const auto M = Mats::M(E, W);
-  // small mode: Hessian in registers; big mode: it reuses the factor buffer
-  // (the factor of M is dead once qacc_smooth has been solved)
   const RegMat H{Hreg};
+  // the factor of M is dead once qacc_smooth has been solved: its registers
+  // take the factor of the Hessian
+  const RegMat F = Mats::L(E, W);
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
   symv(Ma, M, E.qacc);
+  DMC_UNROLL
+  for (int i = 0; i < NM; i++) H.set(i, M.get(i));
   real improvement = 0, alpha_prev = 0;
   int iter = 0;
-  // Every pass over the rows costs an LDS round trip per row that a lone wave
-  // cannot hide, so the passes are fused: (A) applies the previous step to
-  // Jaref, detects active-set changes and accumulates forces, gradient and
-  // Hessian; (B) computes Jv and the line-search quantities at alpha = 0.
   for (;; iter++) {
-    DMC_UNROLL
-    for (int i = 0; i < NM; i++) H.set(i, M.get(i));
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
     bool changed = false;
@@ -1345,18 +1274,27 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
       real row[NVX];
       DMC_UNROLL
       for (int j = 0; j < NV; j++) row[j] = rec.get(j);
-        if (iter > 0) {
-        const real x1 = jar + alpha_prev*jv;
-        changed |= (jar < 0) != (x1 < 0);
-        rec.set(ROW_JAR, x1);
-        jar = x1;
+      bool was = false;                 // is this row's term in H?
+      if (iter > 0) {
+        was = jar < 0;
+        jar += alpha_prev*jv;
+        rec.set(ROW_JAR, jar);
+      } else if (start_smooth) {
+        jar = jv;
+        rec.set(ROW_JAR, jar);
       }
-      if (jar < 0) {
+      const bool now = jar < 0;
+      if (now) {
         const real f = -D*jar;
         DMC_UNROLL
+        for (int j = 0; j < NV; j++) E.qfrc_constraint[j] += row[j]*f;
+      }
+      if (now != was) {
+        changed = true;
+        const real Ds = now ? D : -D;
+        DMC_UNROLL
         for (int j = 0; j < NV; j++) {
-          E.qfrc_constraint[j] += row[j]*f;
-          const real s = D*row[j];
+          const real s = Ds*row[j];
           DMC_UNROLL
           for (int k = 0; k <= j; k++) H.set(tri(j, k), H.get(tri(j, k)) + s*row[k]);
         }
@@ -1375,10 +1313,12 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
     SPROF(0);
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
-    chol_factor(H);
+    DMC_UNROLL
+    for (int i = 0; i < NM; i++) F.set(i, H.get(i));
+    chol_factor(F);
     DMC_UNROLL
     for (int i = 0; i < NV; i++) search[i] = -grad[i];
-    chol_solve(search, H);
+    chol_solve(search, F);
     SPROF(1);
     real sn = 0;
     DMC_UNROLL
@@ -1394,8 +1334,10 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
       q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
       q2 += R(0.5)*search[i]*Mv[i];
     }
-    // pass B: Jv, and the derivatives of the cost along `search` at alpha = 0
+    // pass B: Jv, the derivatives of the cost along `search` at alpha = 0 and
+    // (fp32) the line-search point alpha = 1
     LsPoint p0, p, best;
+    p.alpha = 1; p.dcost = q2 + q1; p.d0 = 2*q2 + q1; p.d1 = 2*q2;
     {
       real d0 = q1, d1 = 2*q2;
       for_rows(W, nefc, [&](auto rec) {
@@ -1403,24 +1345,32 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
         DMC_UNROLL
         for (int j = 0; j < NV; j++) row[j] = rec.get(j);
         const real x0 = rec.get(ROW_JAR), D = rec.get(ROW_D);
-            real sacc = 0;
+        real sacc = 0;
         DMC_UNROLL
         for (int j = 0; j < NV; j++) sacc += row[j]*search[j];
         rec.set(ROW_JV, sacc);
-        if (x0 < 0) { d0 += D*x0*sacc; d1 += D*sacc*sacc; }
+        const real Dv = D*sacc;
+        if (x0 < 0) { d0 += Dv*x0; d1 += Dv*sacc; }
+        if (DMC_F32_RULES) {
+          const real x = x0 + sacc;
+          const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
+          p.dcost += R(0.5)*D*(a*a - a0*a0);
+          if (x < 0) { p.d0 += Dv*x; p.d1 += Dv*sacc; }
+        }
       });
       p0.alpha = 0; p0.dcost = 0; p0.d0 = d0;
       p0.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+      p.d1 = p.d1 > DMC_MINVAL ? p.d1 : DMC_MINVAL;
     }
     SPROF(2);
     // exact line search: safeguarded Newton on the directional derivative
     if (!(p0.d0 < 0)) break;
     best = p0;
-    real lo = 0, hi = 0, a = -p0.d0/p0.d1;
+    real lo = 0, hi = 0, a = DMC_F32_RULES ? R(1) : -p0.d0/p0.d1;
     bool have_hi = false;
     const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
     for (int it = 0; it < DMC_LS_MAXIT; it++) {
-      ls_eval(p, a, E, W, q1, q2);
+      if (!(DMC_F32_RULES && it == 0)) { ls_eval(p, a, E, W, q1, q2); SCOUNT(5); }
       if (p.dcost < best.dcost) best = p;
       if (fabs(p.d0) < dtol) break;
       if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
@@ -1446,295 +1396,14 @@ DEV void solve_newton(Env& E, const Work& W, real tol) {
 }
 
 // ---------------------------------------------------------------------------
-// Row-parallel form of the same solver (ROWPAR): the per-env algorithm above,
-// unchanged, but every pass over the constraint rows is executed by the whole
-// wavefront over the packed row store (for_slots: one row per lane and round,
-// whatever env it belongs to), and what the pass sums per env goes through LDS
-// float atomics into the env's words of the exchange buffer.  Env-indexed
-// work (Cholesky, step acceptance, stopping rules) stays one env per lane.
-// Cost per pass: ceil(rows of the wave / 64) rounds, not max_env(rows) rounds.
-// ---------------------------------------------------------------------------
-#ifndef DMC_HOST_SHIM
-// lanes of the (single-wave) workgroup hand LDS data over: the LDS queue is in
-// order within a wave, the fences pin the compiler and drain the counters
-DEV void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-DEV bool wany(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
-DEV int wshfl_up(int v, int d) { return __shfl_up(v, d, 64); }
-DEV int wbcast(int v, int src) { return __shfl(v, src, 64); }
-DEV void lds_add(real* p, real v) {
-  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-#endif
-// read an accumulator and leave it zero for the next pass
-DEV real take(real* p) { const real v = *p; *p = 0; return v; }
-
-// exclusive prefix sum of `cnt` over the lanes of the workgroup -> packed slots
-DEV void reserve_rows(Work& W, int cnt) {
-  int incl = cnt;
-  DMC_UNROLL
-  for (int d = 1; d < LANES; d <<= 1) {
-    const int t = wshfl_up(incl, d);
-    if (W.lane >= d) incl += t;
-  }
-  W.cnt = cnt;
-  W.base = incl - cnt;
-  W.total = wbcast(incl, LANES - 1);
-}
-
-// warm start: cost of the previous qacc against the unconstrained acceleration;
-// leaves Jaref of the warm start in ROW_JAR and of qacc_smooth in ROW_JV and
-// returns whether the warm start is used (the first pass A of the solver moves
-// ROW_JV into ROW_JAR for the envs that start from qacc_smooth)
-DEV bool warmstart_rp(Env& E, const Work& W, bool has_rows) {
-  const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
-  real cw = 0;
-  if (try_warm && has_rows) {
-    real Ma[NVX];
-    symv(Ma, RegMat{E.qM}, E.warm);
-    DMC_UNROLL
-    for (int i = 0; i < NV; i++)
-      cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
-  }
-  DMC_UNROLL
-  for (int i = 0; i < NV; i++) {
-    *W.eb(EB_VEC + i) = E.warm[i];
-    *W.eb(EB_ACC + 2 + i) = E.qacc_smooth[i];
-  }
-  wsync();
-  for_slots(W, [&](auto rec) {
-    const int e = (int)rec.get(ROW_ENV);
-    real row[NVX];
-    DMC_UNROLL
-    for (int j = 0; j < NV; j++) row[j] = rec.get(j);
-    const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
-    real jw = 0, js = 0;
-    DMC_UNROLL
-    for (int j = 0; j < NV; j++) {
-      jw += row[j]*(*W.eb_of(EB_VEC + j, e));
-      js += row[j]*(*W.eb_of(EB_ACC + 2 + j, e));
-    }
-    jw -= aref; js -= aref;
-    rec.set(ROW_JAR, jw); rec.set(ROW_JV, js);
-    // (the sums land in words 0 and 1; qacc_smooth is parked from word 2 on)
-    if (jw < 0) lds_add(W.eb_of(EB_ACC, e), R(0.5)*D*jw*jw);
-    if (js < 0) lds_add(W.eb_of(EB_ACC + 1, e), R(0.5)*D*js*js);
-  });
-  wsync();
-  cw += take(W.eb(EB_ACC));
-  const real cs = take(W.eb(EB_ACC + 1));
-  DMC_UNROLL
-  for (int i = 0; i < NV; i++) *W.eb(EB_ACC + 2 + i) = 0;
-  return try_warm && !(cw > cs);
-}
-
-DEV void solve_newton_rp(Env& E, const Work& W, real tol, bool active, bool use_warm) {
-#ifdef DMC_SOLVER_PROFILE
-  long long tl_ = wall_clock64();
-#endif
-  real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], Hreg[MAT_REGS];
-  const RegMat M{E.qM};
-  const RegMat H{Hreg};
-  const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
-  symv(Ma, M, E.qacc);
-  DMC_UNROLL
-  for (int i = 0; i < NV; i++) { Mv[i] = 0; search[i] = 0; }
-  real improvement = 0, alpha_prev = 0, q1 = 0, q2 = 0, gtol = 0;
-  for (int iter = 0;; iter++) {      // `iter` is the same for every env still active
-    // at iter 0 the "step" word selects the starting point instead: != 0 means
-    // Jaref <- the qacc_smooth candidate parked in ROW_JV
-    *W.eb(EB_ALPHA) = iter == 0 ? (use_warm ? R(0) : R(1)) : alpha_prev;
-    *W.eb(EB_ACTIVE) = active ? R(1) : R(0);
-    wsync();
-    // pass A: apply the previous step to Jaref, note active-set changes,
-    // accumulate constraint force and Hessian terms of the active rows
-    for_slots(W, [&](auto rec) {
-      const int e = (int)rec.get(ROW_ENV);
-      if (*W.eb_of(EB_ACTIVE, e) == 0) return;
-      real jar = rec.get(ROW_JAR);
-      const real jv = rec.get(ROW_JV), D = rec.get(ROW_D);
-      const real al = *W.eb_of(EB_ALPHA, e);
-      real row[NVX];
-      DMC_UNROLL
-      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
-      if (iter == 0) {
-        if (al != 0) { jar = jv; rec.set(ROW_JAR, jar); }
-      } else {
-        const real x1 = jar + al*jv;
-        if ((jar < 0) != (x1 < 0)) lds_add(W.eb_of(EB_ACC + NM + NV, e), R(1));
-        rec.set(ROW_JAR, x1);
-        jar = x1;
-      }
-      if (jar < 0) {
-        const real f = -D*jar;
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) {
-          lds_add(W.eb_of(EB_ACC + NM + j, e), row[j]*f);
-          const real s = D*row[j];
-          DMC_UNROLL
-          for (int k = 0; k <= j; k++) lds_add(W.eb_of(EB_ACC + tri(j, k), e), s*row[k]);
-        }
-      }
-    });
-    wsync();
-    SPROF(0);
-    if (active) {
-      DMC_UNROLL
-      for (int i = 0; i < NM; i++) H.set(i, M.get(i) + take(W.eb(EB_ACC + i)));
-      DMC_UNROLL
-      for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = take(W.eb(EB_ACC + NM + i));
-      const bool changed = take(W.eb(EB_ACC + NM + NV)) != 0;
-      // fp32: after a full step that left the active set unchanged the iterate
-      // is the exact minimiser of the current quadratic piece
-      const bool converged = DMC_F32_RULES && iter > 0 && !changed &&
-                             fabs(alpha_prev - 1) < R(1e-3);
-      real gn = 0;
-      DMC_UNROLL
-      for (int i = 0; i < NV; i++) {
-        grad[i] = Ma[i] - E.qfrc_smooth[i] - E.qfrc_constraint[i];
-        gn += grad[i]*grad[i];
-      }
-      if ((iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) ||
-          iter >= ITERATIONS) {
-        active = false; E.iters = iter;
-      } else {
-        chol_factor(H);
-        DMC_UNROLL
-        for (int i = 0; i < NV; i++) search[i] = -grad[i];
-        chol_solve(search, H);
-        real sn = 0;
-        DMC_UNROLL
-        for (int i = 0; i < NV; i++) sn += search[i]*search[i];
-        sn = sqrt(sn);
-        alpha_prev = 0;
-        if (sn < DMC_MINVAL) {
-          active = false; E.iters = iter;
-        } else {
-          gtol = tol*R(0.01)*sn/scale;
-          symv(Mv, M, search);
-          q1 = 0; q2 = 0;
-          DMC_UNROLL
-          for (int i = 0; i < NV; i++) {
-            q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
-            q2 += R(0.5)*search[i]*Mv[i];
-            *W.eb(EB_VEC + i) = search[i];
-          }
-        }
-      }
-    }
-    SPROF(1);
-    if (!wany(active)) break;
-    *W.eb(EB_ACTIVE) = active ? R(1) : R(0);
-    wsync();
-    // pass B: Jv, and the derivatives of the cost along `search` at alpha = 0
-    for_slots(W, [&](auto rec) {
-      const int e = (int)rec.get(ROW_ENV);
-      if (*W.eb_of(EB_ACTIVE, e) == 0) return;
-      real row[NVX];
-      DMC_UNROLL
-      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
-      const real x0 = rec.get(ROW_JAR), D = rec.get(ROW_D);
-      real sacc = 0;
-      DMC_UNROLL
-      for (int j = 0; j < NV; j++) sacc += row[j]*(*W.eb_of(EB_VEC + j, e));
-      rec.set(ROW_JV, sacc);
-      if (x0 < 0) {
-        lds_add(W.eb_of(EB_ACC, e), D*x0*sacc);
-        lds_add(W.eb_of(EB_ACC + 1, e), D*sacc*sacc);
-      }
-    });
-    wsync();
-    SPROF(2);
-    // exact line search: safeguarded Newton on the directional derivative,
-    // every env with its own bracket; one pass over the rows per evaluation
-    LsPoint p0, p, best;
-    real lo = 0, hi = 0, a = 0, dtol = 0;
-    bool have_hi = false, ls = false;
-    p0.alpha = 0; p0.dcost = 0; p0.d0 = 0; p0.d1 = 1;
-    best = p0;
-    if (active) {
-      p0.d0 = q1 + take(W.eb(EB_ACC));
-      const real d1 = 2*q2 + take(W.eb(EB_ACC + 1));
-      p0.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
-      if (!(p0.d0 < 0)) {
-        active = false; E.iters = iter;
-      } else {
-        best = p0;
-        a = -p0.d0/p0.d1;
-        dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
-        ls = true;
-      }
-    }
-    for (int it = 0; it < DMC_LS_MAXIT; it++) {
-      if (!wany(ls)) break;
-      *W.eb(EB_ALPHA) = a;
-      *W.eb(EB_ACTIVE) = ls ? R(1) : R(0);
-      wsync();
-      for_slots(W, [&](auto rec) {
-        const int e = (int)rec.get(ROW_ENV);
-        if (*W.eb_of(EB_ACTIVE, e) == 0) return;
-        const real x0 = rec.get(ROW_JAR), v = rec.get(ROW_JV), D = rec.get(ROW_D);
-        const real x = x0 + (*W.eb_of(EB_ALPHA, e))*v;
-        const real xa = x < 0 ? x : R(0), xa0 = x0 < 0 ? x0 : R(0);
-        if (x < 0 || x0 < 0) lds_add(W.eb_of(EB_ACC, e), R(0.5)*D*(xa*xa - xa0*xa0));
-        if (x < 0) {
-          lds_add(W.eb_of(EB_ACC + 1, e), D*x*v);
-          lds_add(W.eb_of(EB_ACC + 2, e), D*v*v);
-        }
-      });
-      wsync();
-      if (ls) {
-        p.alpha = a;
-        p.dcost = a*a*q2 + a*q1 + take(W.eb(EB_ACC));
-        p.d0 = 2*a*q2 + q1 + take(W.eb(EB_ACC + 1));
-        const real d1 = 2*q2 + take(W.eb(EB_ACC + 2));
-        p.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
-        if (p.dcost < best.dcost) best = p;
-        if (fabs(p.d0) < dtol) {
-          ls = false;
-        } else {
-          if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
-          real an = a - p.d0/p.d1;
-          if (have_hi) {
-            if (!(an > lo && an < hi)) an = R(0.5)*(lo + hi);
-            if (hi - lo < R(1e-6)*hi) ls = false;
-          } else if (an <= lo) {
-            an = 2*a;
-          }
-          if (ls) a = an;
-        }
-      }
-    }
-    SPROF(3);
-    if (active) {
-      const real alpha = best.alpha;
-      if (alpha == 0) {
-        active = false; E.iters = iter;
-      } else {
-        improvement = -best.dcost;
-        DMC_UNROLL
-        for (int i = 0; i < NV; i++) { E.qacc[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
-        alpha_prev = alpha;           // applied to Jaref by the next pass A
-      }
-    }
-    SPROF(4);
-    if (!wany(active)) break;
-  }
-}
-
-// ---------------------------------------------------------------------------
 // touch sensors (mjSENS_TOUCH in mj_sensorAcc): sum of the normal forces of the
 // contacts that involve the sensor site's body and whose force ray, cast from
 // the contact point, meets the site's spherical zone
 // ---------------------------------------------------------------------------
 DEV real row_force(const Work& W, int r) {
   real jar, D;
-  const int s = W.slot(r);
-  if (W.in_lds(s)) { jar = W.lslot(s).get(ROW_JAR); D = W.lslot(s).get(ROW_D); }
-  else { jar = W.gslot(s).get(ROW_JAR); D = W.gslot(s).get(ROW_D); }
+  if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS) { jar = W.lrow(r).get(ROW_JAR); D = W.lrow(r).get(ROW_D); }
+  else { jar = W.grow(r).get(ROW_JAR); D = W.grow(r).get(ROW_D); }
   return jar < 0 ? -D*jar : R(0);
 }
 // smallest t >= 0 with |o + t d| = radius (d unit), or -1
@@ -1746,6 +1415,25 @@ DEV real ray_sphere(const real* o, const real* d, real radius) {
   if (-b - sq >= 0) return -b - sq;
   if (-b + sq >= 0) return -b + sq;
   return -1;
+}
+// smallest t >= 0 at which o + t d meets a face of the box |x_i| <= size_i, or -1
+// (a ray that runs along a face or an edge counts, as in mju_rayGeom: the
+// contact points of a box resting on a plane sit on the edges of a box site)
+DEV real ray_box(const real* o, const real* d, const real* size) {
+  real best = -1;
+  DMC_UNROLL
+  for (int i = 0; i < 3; i++) {
+    if (fabs(d[i]) < DMC_MINVAL) continue;
+    const int j = (i + 1) % 3, k = (i + 2) % 3;
+    DMC_UNROLL
+    for (int side = -1; side <= 1; side += 2) {
+      const real t = (side*size[i] - o[i])/d[i];
+      if (t < 0) continue;
+      const real pj = o[j] + t*d[j], pk = o[k] + t*d[k];
+      if (fabs(pj) <= size[j] && fabs(pk) <= size[k] && (best < 0 || t < best)) best = t;
+    }
+  }
+  return best;
 }
 template <class EnvT>
 DEV real touch_hit(const EnvT& E, int s, const real* pos, const real* normal,
@@ -1761,7 +1449,23 @@ DEV real touch_hit(const EnvT& E, int s, const real* pos, const real* normal,
     o[k] = pos[k] - site;
     d[k] = body == b2 ? -normal[k] : normal[k];   // ray flips if the sensor is on body 2
   }
-  return ray_sphere(o, d, R(touch_radius[s])) >= 0 ? R(1) : R(0);
+  if (touch_type[s] == GEOM_BOX) {
+    // into the site frame: world <- body (xmat) <- site (touch_mat)
+    real ob[3], db[3], ol[3], dl[3];
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      ob[k] = E.xmat[9*body + k]*o[0] + E.xmat[9*body + 3 + k]*o[1] + E.xmat[9*body + 6 + k]*o[2];
+      db[k] = E.xmat[9*body + k]*d[0] + E.xmat[9*body + 3 + k]*d[1] + E.xmat[9*body + 6 + k]*d[2];
+    }
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      ol[k] = R(touch_mat[9*s + k])*ob[0] + R(touch_mat[9*s + 3 + k])*ob[1] + R(touch_mat[9*s + 6 + k])*ob[2];
+      dl[k] = R(touch_mat[9*s + k])*db[0] + R(touch_mat[9*s + 3 + k])*db[1] + R(touch_mat[9*s + 6 + k])*db[2];
+    }
+    const real size[3] = {R(touch_size[3*s]), R(touch_size[3*s + 1]), R(touch_size[3*s + 2])};
+    return ray_box(ol, dl, size) >= 0 ? R(1) : R(0);
+  }
+  return ray_sphere(o, d, R(touch_size[3*s])) >= 0 ? R(1) : R(0);
 }
 template <class Rec>
 DEV void touch_of_contact(Env& E, const Work& W, const Rec& rec, int& r) {
@@ -1792,56 +1496,26 @@ DEV void touch_sensors(Env& E, const Work& W) {
     for (int k = LDS_CONS; k < E.ncon; k++) touch_of_contact(E, W, W.gcon(k), r);
 }
 
-// forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms.
-// ROWPAR: called by every lane of the workgroup at the same point (the solver
-// passes are executed by the whole wavefront); `rows_ok` false keeps this env
-// out of the constraint stage (surplus lanes of a partial last workgroup).
-DEV void forward(Env& E, Work& W, bool actuation, real tol, bool rows_ok = true) {
+// forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms
+DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
   kinematics(E);
   com_pos(E);
   crb_factor(E, W);
   com_vel(E);
   smooth_forces(E, W, actuation);
   E.ncon = 0; E.nefc = 0; E.iters = 0;
-#ifdef DMC_ABLATE_CONTACT
-  const bool with_contacts = false;
-#else
-  const bool with_contacts = NPAIR > 0;
-#endif
-  if (with_contacts) detect_contacts(E, W);
-  if (ROWPAR) {
-    // reserve this env's slots in the packed row store before building rows
-    int cnt = count_limit_rows(E) + (with_contacts ? count_contact_rows(E, W) : 0);
-    if (cnt > NEFC_MAX) cnt = NEFC_MAX;
-    reserve_rows(W, rows_ok ? cnt : 0);
-  }
   limit_rows(E, W);
   E.nefc_limit = E.nefc;
-  if (with_contacts) contact_rows(E, W);
-  if (ROWPAR) {
-    // (count_* mirror the builders; should they ever disagree, keep the store consistent)
-    real zero[NVX];
-    DMC_UNROLL
-    for (int j = 0; j < NV; j++) zero[j] = 0;
-    while (E.nefc < W.cnt) push_row(E, W, zero, 0, 0, 0, 0, R(1e30));
-    if (E.nefc_limit > E.nefc) E.nefc_limit = E.nefc;
-  }
+#ifndef DMC_ABLATE_CONTACT
+  if (NPAIR > 0) contact_rows(E, W);
+#endif
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
 #ifdef DMC_ABLATE_SOLVER
-  const bool solve = false;
+  if (true) {
 #else
-  const bool solve = true;
+  if (E.nefc == 0) {
 #endif
-  if (ROWPAR && solve) {
-    const bool has_rows = E.nefc > 0;
-    bool use_warm = false;
-    if (W.total > 0) use_warm = warmstart_rp(E, W, has_rows);   // wave-uniform branch
-    DMC_UNROLL
-    for (int i = 0; i < NV; i++)
-      E.qacc[i] = has_rows && use_warm ? E.warm[i] : E.qacc_smooth[i];
-    if (W.total > 0) solve_newton_rp(E, W, tol, has_rows, use_warm);
-  } else if (E.nefc == 0 || !solve) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qacc[i] = E.qacc_smooth[i];
   } else {
@@ -1869,15 +1543,9 @@ DEV void forward(Env& E, Work& W, bool actuation, real tol, bool rows_ok = true)
       rec.set(ROW_JAR, jw); rec.set(ROW_JV, js);
     });
     const bool use_warm = try_warm && !(cw > cs);
-    if (use_warm) {
-      DMC_UNROLL
-      for (int i = 0; i < NV; i++) E.qacc[i] = E.warm[i];
-    } else {
-      DMC_UNROLL
-      for (int i = 0; i < NV; i++) E.qacc[i] = E.qacc_smooth[i];
-      for_rows(W, E.nefc, [&](auto rec) { rec.set(ROW_JAR, rec.get(ROW_JV)); });
-    }
-    solve_newton(E, W, tol);
+    DMC_UNROLL
+    for (int i = 0; i < NV; i++) E.qacc[i] = use_warm ? E.warm[i] : E.qacc_smooth[i];
+    solve_newton(E, W, tol, !use_warm);
   }
   if (NTOUCH > 0) touch_sensors(E, W);
   DMC_UNROLL
@@ -1972,8 +1640,7 @@ DEV bool check_state(Env& E, real& time) {   // mj_checkPos / mj_checkVel
 // without a forward pass and calls physics.step(), whose mj_step2 still sees
 // the mass matrix, bias forces and contacts of qpos0 (suite/cheetah.py:63-77,
 // engine.py:149-166).
-DEV void physics_step(Env& E, Work& W, real& time, real tol, bool rows_ok,
-                      bool stale = false) {
+DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = false) {
   const real h = R(timestep);
   check_state(E, time);
   if (INTEGRATOR == 0) {
@@ -1984,7 +1651,7 @@ DEV void physics_step(Env& E, Work& W, real& time, real tol, bool rows_ok,
       DMC_UNROLL
       for (int i = 0; i < NV; i++) { vkeep[i] = E.qvel[i]; E.qvel[i] = 0; }
     }
-    forward(E, W, true, tol, rows_ok);
+    forward(E, W, true, tol);
     bool ba = false;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) ba |= bad(E.qacc[i]);
@@ -2032,19 +1699,11 @@ DEV void physics_step(Env& E, Work& W, real& time, real tol, bool rows_ok,
     for (int i = 0; i < NQ; i++) q0[i] = E.qpos[i];
     DMC_UNROLL
     for (int i = 0; i < NV; i++) v0[i] = E.qvel[i];
-    forward(E, W, true, tol, rows_ok);
+    forward(E, W, true, tol);
     bool ba = false;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) ba |= bad(E.qacc[i]);
-    // a bad acceleration resets the state; the lane still walks through the
-    // remaining stages (every lane takes part in the solver passes of forward)
-    if (ba) {
-      E.warn |= WARN_BADQACC; reset_state(E, time);
-      DMC_UNROLL
-      for (int i = 0; i < NQ; i++) q0[i] = E.qpos[i];
-      DMC_UNROLL
-      for (int i = 0; i < NV; i++) { v0[i] = 0; E.qacc[i] = 0; }
-    }
+    if (ba) { E.warn |= WARN_BADQACC; reset_state(E, time); return; }
     DMC_UNROLL
     for (int i = 0; i < NV; i++) { Fv[i] = E.qvel[i]; Fa[i] = E.qacc[i]; }
     const real Acoef[3] = {R(0.5), R(0.5), R(1)};
@@ -2059,11 +1718,10 @@ DEV void physics_step(Env& E, Work& W, real& time, real tol, bool rows_ok,
       DMC_UNROLL
       for (int i = 0; i < NQ; i++) E.qpos[i] = q0[i];
       integrate_pos(E.qpos, dv, h);
-      forward(E, W, true, tol, rows_ok);
+      forward(E, W, true, tol);
       DMC_UNROLL
       for (int i = 0; i < NV; i++) { Fv[s*NV + i] = E.qvel[i]; Fa[s*NV + i] = E.qacc[i]; }
     }
-    if (ba) { reset_state(E, time); return; }
 #ifdef DMC_STATE_COMP
     real acc[NVX];
     DMC_UNROLL
@@ -2341,34 +1999,6 @@ DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
 // helpers above and supplies its own dmc_step / dmc_observe)
 // ---------------------------------------------------------------------------
 #ifndef DMC_COOP_BUILD
-// the workspace is laid out for the batch rounded up to whole workgroups
-DEV long long padded_envs(const DmcArgs& a) {
-  return ((long long)a.nenv + LANES - 1)/LANES*LANES;
-}
-// Surplus lanes of a partial last workgroup stay in the kernel (the solver
-// passes are executed by all lanes of the wavefront): they shadow the last env
-// with no constraint rows of their own and store nothing.
-struct LaneId { int e; long long slot; bool alive; };
-DEV LaneId lane_id(const DmcArgs& a) {
-  const long long raw = (long long)blockIdx.x*blockDim.x + threadIdx.x;
-  const bool alive = raw < a.nenv;
-  return LaneId{alive ? (int)raw : a.nenv - 1, raw, alive};
-}
-DEV Work make_work(const DmcArgs& a, real* lds, const LaneId& id) {
-  Work W;
-  const long long np = padded_envs(a);
-  W.lds0 = lds;
-  W.glb_rows = a.ws + (long long)blockIdx.x*GLB_ROWS*RW*LANES;
-  W.glb = a.ws + id.slot;
-  W.npad = np;
-  W.lane = threadIdx.x;
-  W.base = 0; W.cnt = 0; W.total = 0;
-  if (ROWPAR) {   // the per-env sums start from zero (and are left zero by `take`)
-    DMC_UNROLL
-    for (int k = 0; k < EB_NACC; k++) *W.eb(EB_ACC + k) = 0;
-  }
-  return W;
-}
 DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   const long long n = a.nenv;
   DMC_UNROLL
@@ -2378,7 +2008,7 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   time = a.time[e];
 #ifdef DMC_STATE_COMP
   {
-    const long long np = padded_envs(a);
+    const long long np = n;
     const real* c = a.ws + (long long)WS_COMP*np + e;
     DMC_UNROLL
     for (int i = 0; i < NQ; i++) {
@@ -2411,7 +2041,7 @@ DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
   a.time[e] = time;
 #ifdef DMC_STATE_COMP
   {
-    const long long np = padded_envs(a);
+    const long long np = n;
     real* c = a.ws + (long long)WS_COMP*np + e;
     DMC_UNROLL
     for (int i = 0; i < NQ; i++) { c[i*np] = E.qpos[i]; c[(NQ + i)*np] = E.qpos_lo[i]; }
@@ -2431,7 +2061,7 @@ DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
 constexpr bool OBS_STAGE_FITS = LDS_WORDS >= LANES*(NOBS > 0 ? NOBS : 1);
 
 DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
-                       real* lds_base, bool alive) {
+                       real* lds_base) {
   const long long n = a.nenv;
   real obs[NOBS > 0 ? NOBS : 1];
   const real rew = task_outputs(E, a, obs);
@@ -2444,11 +2074,10 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
     const long long left = n - base;
     const int nvalid = left < (long long)blockDim.x ? (int)left : (int)blockDim.x;
     real* out = a.obs + base*NOBS;
-    for (int w = lane; w < nvalid*NOBS; w += LANES)
+    // lanes 0..nvalid-1 are exactly the active ones of a partial last block
+    for (int w = lane; w < nvalid*NOBS; w += nvalid)
       out[w] = lds_base[(w % NOBS)*LANES + w/NOBS];
-    if (!alive) return;
   } else {
-    if (!alive) return;
     DMC_UNROLL
     for (int k = 0; k < NOBS; k++)
       a.obs[(long long)k*a.obs_sk + (long long)e*a.obs_se] = obs[k];
@@ -2489,8 +2118,8 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
 #endif
 extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_step(DmcArgs a) {
-  const LaneId id = lane_id(a);
-  const int e = id.e;
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= a.nenv) return;
   Env E;
   real time;
   load_env(E, a, e, time);
@@ -2507,20 +2136,18 @@ dmc_step(DmcArgs a) {
       DMC_UNROLL
       for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
     }
-    if (id.alive) {
-      DMC_UNROLL
-      for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
-    }
+    DMC_UNROLL
+    for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
   } else {
     DMC_UNROLL
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
   __shared__ real lds_rows[LDS_WORDS];
-  Work W = make_work(a, lds_rows, id);
+  Work W = {lds_rows + threadIdx.x, a.ws + e, n};
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
   for (int s = 0; s < a.nsub; s++)
-    physics_step(E, W, time, tol, id.alive, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
-  if (a.qacc && id.alive) {
+    physics_step(E, W, time, tol, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
+  if (a.qacc) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];
   }
@@ -2528,21 +2155,20 @@ dmc_step(DmcArgs a) {
 #ifndef DMC_ABLATE_OBS
     observe_stage(E, time);
 #endif
-    store_outputs(E, a, e, true, lds_rows, id.alive);
+    store_outputs(E, a, e, true, lds_rows);
   }
 #ifdef DMC_SOLVER_PROFILE
   __syncthreads();
-  if (id.alive)
-    for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
+  for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
 #endif
-  if (id.alive) store_env(E, a, e, time);
+  store_env(E, a, e, time);
 }
 
 // observation / reward / sensors of the current state (reset, after_reset)
 extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_observe(DmcArgs a) {
-  const LaneId id = lane_id(a);
-  const int e = id.e;
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= a.nenv) return;
   Env E;
   real time;
   load_env(E, a, e, time);
@@ -2550,14 +2176,14 @@ dmc_observe(DmcArgs a) {
   DMC_UNROLL
   for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   __shared__ real lds_rows[LDS_WORDS];
-  Work W = make_work(a, lds_rows, id);
+  Work W = {lds_rows + threadIdx.x, a.ws + e, n};
   if (NTOUCH > 0) {
     // acceleration-stage sensors need the constraint forces: the reference's
     // after_reset runs mj_forward with actuation disabled (engine.py:283-295);
     // a bad state is reset first (mj_checkPos), as mj_forward would see it
     const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
     check_state(E, time);
-    forward(E, W, false, tol, id.alive);
+    forward(E, W, false, tol);
   }
   const int ncon_forward = E.ncon, nefc_forward = E.nefc;
   observe_stage(E, time);
@@ -2567,8 +2193,8 @@ dmc_observe(DmcArgs a) {
     E.ncon = 0; E.nefc = 0;
     if (NPAIR > 0) detect_contacts(E, W);
   }
-  store_outputs(E, a, e, false, lds_rows, id.alive);
-  if (id.alive) store_env(E, a, e, time);
+  store_outputs(E, a, e, false, lds_rows);
+  store_env(E, a, e, time);
 }
 
 #endif  // !DMC_COOP_BUILD

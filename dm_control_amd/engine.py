@@ -611,32 +611,55 @@ class Physics(_control.Physics):
     return new
 
   # -- checkpoints ----------------------------------------------
-  def save_checkpoint(self, path):
-    """Writes the integration state of every instance to an `.npz` file.
+  _CHECKPOINT_FIELDS = (
+      ('qpos', wrapper.FIELD_QPOS), ('qvel', wrapper.FIELD_QVEL),
+      ('qacc_warmstart', wrapper.FIELD_WARMSTART), ('time', wrapper.FIELD_TIME),
+      ('ctrl', wrapper.FIELD_CTRL), ('taskdata', wrapper.FIELD_TASKDATA),
+      ('episode_return', wrapper.FIELD_RETURN), ('warn', wrapper.FIELD_WARN))
 
-    qpos, qvel, qacc_warmstart and time are exactly what `mj_step` carries from
-    one step to the next (the warm start matters: it seeds the Newton solver),
-    so a restored batch continues bit-for-bit under the same actions.
+  @staticmethod
+  def _checkpoint_path(path):
+    path = str(path)
+    return path if path.endswith('.npz') else path + '.npz'
+
+  def save_checkpoint(self, path, step_count=None):
+    """Writes everything the next step depends on to `<path>.npz`.
+
+    qpos, qvel, qacc_warmstart and time are what `mj_step` carries from one
+    step to the next (the warm start seeds the Newton solver); ctrl is the
+    control a step without a new action re-applies; the per-instance task data
+    (reacher target, point_mass directions) is part of the dynamics and of the
+    reward; episode_return and the warning mask complete the bookkeeping.  A
+    restored batch continues bit-for-bit under the same actions.  `step_count`
+    (e.g. `Environment.step_count`) is stored for the caller's episode logic.
     """
     b = self._batch
-    np.savez(path, qpos=b.read(wrapper.FIELD_QPOS), qvel=b.read(wrapper.FIELD_QVEL),
-             qacc_warmstart=b.read(wrapper.FIELD_WARMSTART),
-             time=b.read(wrapper.FIELD_TIME),
+    arrays = {name: b.read(field) for name, field in self._CHECKPOINT_FIELDS}
+    np.savez(self._checkpoint_path(path),
              model_hash=np.array(self.model.content_hash()),
-             precision=np.array(self._precision))
+             precision=np.array(self._precision),
+             step_count=np.array(-1 if step_count is None else int(step_count)),
+             **arrays)
 
   def load_checkpoint(self, path):
-    """Restores a state written by `save_checkpoint` (same model, batch size)."""
-    with np.load(path, allow_pickle=False) as z:
+    """Restores a state written by `save_checkpoint` (same model, precision and
+    batch size); returns the stored step count (None if none was stored)."""
+    with np.load(self._checkpoint_path(path), allow_pickle=False) as z:
       if str(z['model_hash']) != self.model.content_hash():
         raise ValueError('checkpoint was written for a different model')
-      qpos, qvel = z['qpos'], z['qvel']
-      if qpos.shape != (self.model.nq, self._batch_size):
+      if str(z['precision']) != self._precision:
+        raise ValueError('checkpoint was written by a {} build, this batch is {}'
+                         .format(z['precision'], self._precision))
+      if z['qpos'].shape != (self.model.nq, self._batch_size):
         raise ValueError('checkpoint holds {} instances, this batch {}'.format(
-            qpos.shape[-1], self._batch_size))
-      self._batch.set_state(qpos=qpos, qvel=qvel, warmstart=z['qacc_warmstart'],
-                            time=z['time'])
+            z['qpos'].shape[-1], self._batch_size))
+      for name, field in self._CHECKPOINT_FIELDS:
+        self._batch.write(field, z[name])
+      step_count = int(z['step_count'])
+    self._warn_seen = self._batch.read(wrapper.FIELD_WARN).copy()
+    self._pending_ctrl = None
     self._dirty = True
+    return None if step_count < 0 else step_count
 
   def set_task_params(self, iparam=0, rparams=()):
     self._batch.set_task_params(iparam, rparams)

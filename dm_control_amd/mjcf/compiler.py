@@ -1089,11 +1089,7 @@ def from_xml_string(xml_string, assets=None):
   except ET.ParseError as e:
     raise CompileError('XML parse error: %s' % e)
   m = _Compiler(root, assets or {}).compile()
-  # mirror the `model.opt` fields at the top level for the native-field table
-  for key in ('timestep', 'gravity', 'integrator', 'cone', 'solver',
-              'iterations', 'tolerance', 'impratio', 'disableflags',
-              'enableflags'):
-    setattr(m, key, getattr(m.opt, key))
+  # (the `model.opt` fields are also readable at the top level: Model.__getattr__)
   m.opt.meaninertia = m.meaninertia
   return m
 

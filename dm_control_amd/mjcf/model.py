@@ -129,12 +129,33 @@ class Opt:
   """`model.opt` namespace (timestep, gravity, integrator, ...)."""
 
 
+_OPT_FIELDS = ('timestep', 'gravity', 'integrator', 'cone', 'solver',
+               'iterations', 'tolerance', 'impratio', 'disableflags',
+               'enableflags')
+
+
 class Model:
-  """Plain-numpy compiled model with `mjModel` field names."""
+  """Plain-numpy compiled model with `mjModel` field names.
+
+  The `mjOption` fields live in `model.opt`; reading or assigning them at the
+  top level (`model.timestep`) goes to the same object, so the native-field
+  table (oracle) and the code generator (device) can never see two values.
+  """
 
   def __init__(self):
-    self.opt = Opt()
+    object.__setattr__(self, 'opt', Opt())
     self.names = {}  # objtype -> list of names (index = id)
+
+  def __getattr__(self, name):   # only reached when normal lookup fails
+    if name in _OPT_FIELDS and 'opt' in self.__dict__:
+      return getattr(self.__dict__['opt'], name)
+    raise AttributeError(name)
+
+  def __setattr__(self, name, value):
+    if name in _OPT_FIELDS:
+      setattr(self.opt, name, value)
+    else:
+      object.__setattr__(self, name, value)
 
   # -- name lookups (wrapper/core.py:532-574) --------------------------------
   def name2id(self, name, object_type):
@@ -152,7 +173,7 @@ class Model:
     return names[object_id] or ''
 
   def field(self, name):
-    if hasattr(self.opt, name) and not hasattr(self, name):
+    if name in _OPT_FIELDS:
       return getattr(self.opt, name)
     return getattr(self, name)
 

@@ -103,6 +103,17 @@ class Environment(dm_env.Environment):
       return _spec_from_observation(observation)
 
   @property
+  def step_count(self):
+    """Control steps taken in the current episode (the counter behind the
+    time limit, rl/control.py:110-114); assignable when a checkpoint is restored."""
+    return self._step_count
+
+  @step_count.setter
+  def step_count(self, value):
+    self._step_count = int(value)
+    self._reset_next_step = self._step_count >= self._step_limit
+
+  @property
   def physics(self):
     return self._physics
 

@@ -187,7 +187,7 @@ class HipBatch:
 
   def write(self, field, array):
     """Uploads a writable field given as [k][nenv] (any float dtype)."""
-    a = np.ascontiguousarray(array, dtype=self.model.dtype)
+    a = np.ascontiguousarray(array, dtype=self._dtype(field))
     if a.shape != self._shape(field):
       raise ValueError('expected shape {}, got {}'.format(
           self._shape(field), a.shape))

@@ -102,8 +102,31 @@ def oracle_touch(model, d, sensor_name):
   i = model.names['sensor'].index(sensor_name)
   sid = int(model.sensor_objid[i])
   body = int(model.site_bodyid[sid])
-  centre = d.xpos[body] + d.xmat[body].reshape(3, 3).dot(model.site_pos[sid])
-  radius = model.site_size[sid][0]
+  rot_body = d.xmat[body].reshape(3, 3)
+  centre = d.xpos[body] + rot_body.dot(model.site_pos[sid])
+  w, x, y, z = model.site_quat[sid]
+  rot_site = rot_body.dot(np.array(
+      [[w*w + x*x - y*y - z*z, 2*(x*y - w*z), 2*(x*z + w*y)],
+       [2*(x*y + w*z), w*w - x*x + y*y - z*z, 2*(y*z - w*x)],
+       [2*(x*z - w*y), 2*(y*z + w*x), w*w - x*x - y*y + z*z]]))
+  size = model.site_size[sid]
+  is_box = int(model.site_type[sid]) == 6
+
+  def meets_zone(origin, ray):
+    if not is_box:
+      b, cc = origin.dot(ray), origin.dot(origin) - size[0]*size[0]
+      disc = b*b - cc
+      return disc >= 0 and (-b - np.sqrt(disc) >= 0 or -b + np.sqrt(disc) >= 0)
+    o, r = rot_site.T.dot(origin), rot_site.T.dot(ray)
+    for i in range(3):
+      if abs(r[i]) < 1e-15:
+        continue
+      j, k = (i + 1) % 3, (i + 2) % 3
+      for side in (-1, 1):
+        t = (side*size[i] - o[i])/r[i]
+        if t >= 0 and abs(o[j] + t*r[j]) <= size[j] and abs(o[k] + t*r[k]) <= size[k]:
+          return True
+    return False
   total = 0.0
   for c in range(d.ncon):
     con = d.contact(c)
@@ -115,11 +138,6 @@ def oracle_touch(model, d, sensor_name):
     if fn <= 0:
       continue
     ray = con['frame'][0] * (-1.0 if body == b2 else 1.0)
-    o = con['pos'] - centre
-    b, cc = o.dot(ray), o.dot(o) - radius*radius
-    disc = b*b - cc
-    if disc < 0:
-      continue
-    if -b - np.sqrt(disc) >= 0 or -b + np.sqrt(disc) >= 0:
+    if meets_zone(con['pos'] - centre, ray):
       total += fn
   return total

@@ -12,7 +12,7 @@ int main(int argc, char** argv) {
   std::vector<real> qpos(nq), qvel(nv, 0), warm(nv, 0), tm(1, 0), ctrl(nu, 0),
       obs(NOBS > 0 ? NOBS : 1), rew(1), ret(1), sens(NSENSORDATA > 0 ? NSENSORDATA : 1),
       xpos(NBODY*3), xmat(NBODY*9), qacc(nv),
-      ws((WS_WORDS > 0 ? WS_WORDS : 1)*64, 0);   // laid out for a whole workgroup
+      ws((WS_WORDS > 0 ? WS_WORDS : 1));
   std::vector<unsigned> warn(1, 0);
   std::vector<int> stats(3, 0);
   for (int i = 0; i < NQ; i++) qpos[i] = (real)qpos0[i];

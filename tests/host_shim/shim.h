@@ -20,10 +20,3 @@ static inline void __syncthreads() {}
 using std::sqrt; using std::fabs; using std::pow; using std::exp; using std::log;
 using std::cos; using std::sin; using std::fmax; using std::fmin; using std::log1p;
 // glibc already declares sincos/sincosf with the signatures the kernel uses
-// one lane only: the wave primitives of the row-parallel solver degenerate
-// (this harness builds with -DDMC_ROWPAR=0, the per-lane solver)
-static inline void wsync() {}
-static inline bool wany(bool p) { return p; }
-static inline int wshfl_up(int v, int) { return v; }
-static inline int wbcast(int v, int) { return v; }
-template <class T> static inline void lds_add(T* p, T v) { *p += v; }

@@ -54,11 +54,3 @@ template <class T> static inline T gup(T x, int d) {
 }
 template <class T> static inline T gget(T x, int src) { return shim_xchg(x, src); }
 template <class T> static inline T gbcast(T x, int src) { return shim_xchg(x, src); }
-// wave primitives of the one-env-per-lane kernel's row-parallel solver: the
-// several-lanes-per-env source includes that file for its helpers only and
-// never calls them
-static inline void wsync() {}
-static inline bool wany(bool p) { return p; }
-static inline int wshfl_up(int v, int) { return v; }
-static inline int wbcast(int v, int) { return v; }
-template <class T> static inline void lds_add(T* p, T v) { *p += v; }

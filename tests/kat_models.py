@@ -117,3 +117,109 @@ GPU_MODELS = {
     'ball_on_floor': BALL_ON_FLOOR,
     'primitives': PRIMITIVES,
 }
+
+# K2 with its sensor (wrapper/core_test.py:329-344): the touch site covers the cube
+CUBE_WITH_TOUCH = """
+<mujoco>
+  <option gravity="0 0 -9.81"/>
+  <worldbody>
+    <geom name="floor" type="plane" pos="0 0 0" size="10 10 0.1"/>
+    <body name="cube" pos="0 0 0.1">
+      <geom type="box" size="0.1 0.1 0.1" mass="1"/>
+      <site name="cube_site" type="box" size="0.1 0.1 0.1"/>
+      <joint type="slide"/>
+    </body>
+  </worldbody>
+  <sensor>
+    <touch name="touch_sensor" site="cube_site"/>
+  </sensor>
+</mujoco>
+"""
+
+# ---------------------------------------------------------------------------
+# Models of the reference-independent closed-form checks (SURVEY.md Appendix D,
+# tests/test_closed_form.py).  Each is a suite model with the terms that would
+# break the invariant switched off in the compiled arrays; the GPU twin runs
+# the same models through fp64 code objects (__graft_entry__.build()).
+# ---------------------------------------------------------------------------
+OSCILLATOR = """
+<mujoco>
+  <option timestep="0.01" gravity="0 0 0"/>
+  <worldbody>
+    <body name="mass" pos="0 0 0">
+      <joint name="x" type="slide" axis="1 0 0" stiffness="30" damping="1.5"/>
+      <geom type="sphere" size="0.1" mass="2"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+CAPSULE_PAIR = """
+<mujoco>
+  <option gravity="0 0 0"/>
+  <worldbody>
+    <body name="a" pos="0 0 0">
+      <freejoint/>
+      <geom name="a" type="capsule" size="0.07 0.3" margin="5"/>
+    </body>
+    <body name="b" pos="0 0 1">
+      <freejoint/>
+      <geom name="b" type="capsule" size="0.05 0.2" margin="5"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+CAPSULE_OVER_PLANE = """
+<mujoco>
+  <option gravity="0 0 0"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="5 5 .1" margin="5"/>
+    <body name="a" pos="0 0 1">
+      <freejoint/>
+      <geom name="a" type="capsule" size="0.07 0.3" margin="5"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def closed_form_models():
+  """name -> (compiled Model, build mode of its fp64 device code object)."""
+  import numpy as np
+  import helpers
+  from dm_control_amd.mjcf import compiler
+  from dm_control_amd.mjcf import model as mdl
+  out = {}
+
+  def frictionless(m, integrator):
+    """No dissipation, no actuation, no contacts or limits."""
+    m.dof_damping[:] = 0
+    m.jnt_stiffness[:] = 0
+    m.opt.disableflags |= (mdl.DSBL_CONTACT | mdl.DSBL_LIMIT | mdl.DSBL_ACTUATION)
+    m.opt.integrator = integrator
+    return m
+
+  for integ, tag, dt_scale in ((1, 'rk4', 1.0), (0, 'euler', 1.0), (0, 'euler_half', 0.5)):
+    for name, key in (('cheetah', 'cheetah_chain_'), ('acrobot', 'acrobot_')):
+      m = frictionless(helpers.load_model(name), integ)
+      m.opt.timestep = m.opt.timestep*dt_scale
+      out[key + tag] = (m, 'auto')
+  # humanoid adrift: no gravity, no contacts; joint limits, damping and motors
+  # are internal forces and keep the momentum
+  for tag, dt_scale in (('', 1.0), ('_half', 0.5)):
+    h = helpers.load_model('humanoid')
+    h.opt.gravity[:] = 0
+    h.opt.disableflags |= mdl.DSBL_CONTACT
+    h.opt.integrator = 1
+    h.opt.timestep = h.opt.timestep*dt_scale
+    out['humanoid_adrift' + tag] = (h, 'coop')
+  out['oscillator'] = (compiler.from_xml_string(OSCILLATOR), 'auto')
+  # cart-pole pushed against its slider limit; a stiff hinge damper lets the
+  # pole come to rest quickly (the limit's solref/solimp are the reference's)
+  c = helpers.load_model('cartpole')
+  c.dof_damping[1] = 0.5
+  c.opt.integrator = 0
+  out['cartpole_at_limit'] = (c, 'auto')
+  out['cube_with_touch'] = (compiler.from_xml_string(CUBE_WITH_TOUCH), 'auto')
+  return out

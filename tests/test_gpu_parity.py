@@ -170,6 +170,36 @@ def test_touch_sensors_match_oracle(mode):
   hb.free()
 
 
+def test_first_timestep_touch_of_a_hopper_in_contact():
+  """The FIRST TimeStep's `touch` observation: the reference's after_reset runs
+  mj_forward with actuation disabled (engine.py:283-295), so the touch sensors
+  of the randomised start pose -- random ankle angles put the toe through the
+  floor -- hold the contact forces of that pose, not zero."""
+  nenv = 64
+  env = suite.load('hopper', 'stand', task_kwargs={'random': 3},
+                   environment_kwargs={'batch_size': nenv, 'precision': 'f64'})
+  ts = env.reset()
+  physics = env.physics
+  model = physics.model
+  qpos = np.asarray(physics.data.qpos)
+  qvel = np.asarray(physics.data.qvel)
+  want = np.zeros((nenv, 2))
+  for i in range(nenv):
+    p = oracle.OraclePhysics(model)
+    p.reset()
+    p.data.qpos[:] = qpos[i]
+    p.data.qvel[:] = qvel[i]
+    p.after_reset()
+    want[i] = [helpers.oracle_touch(model, p.data, n)
+               for n in ('touch_toe', 'touch_heel')]
+  assert (want > 0).sum() > nenv//4            # many start poses touch the floor
+  np.testing.assert_allclose(ts.observation['touch'], np.log1p(want),
+                             rtol=1e-6, atol=1e-9)
+  assert np.array_equal(physics.data.ncon > 0, (want.sum(axis=1) > 0) |
+                        (np.asarray(physics.data.ncon) > 0))
+  physics.free()
+
+
 @pytest.mark.parametrize('lds_budget', [64*1024, 36*1024])
 def test_high_occupancy_variants_match_oracle(lds_budget):
   """The code objects `build.lds_budget_for` picks for batches > 16384 envs
@@ -571,7 +601,54 @@ def test_checkpoint_round_trip_continues_bit_for_bit(tmp_path):
   small = suite.load('cheetah', 'run', environment_kwargs={'batch_size': 4})
   with pytest.raises(ValueError):
     small.physics.load_checkpoint(path)
-  for e in (env, other, small):
+  wide = suite.load('cheetah', 'run', environment_kwargs={
+      'batch_size': 96, 'precision': 'f64'})
+  with pytest.raises(ValueError):
+    wide.physics.load_checkpoint(path)              # precision mismatch
+  for e in (env, other, small, wide):
+    e.physics.free()
+
+
+@pytest.mark.parametrize('domain,task', [('reacher', 'hard'), ('point_mass', 'hard')])
+def test_checkpoint_restores_task_data_control_and_bookkeeping(domain, task, tmp_path):
+  """The per-instance task data (reacher target, point_mass actuation
+  directions) is part of the dynamics and of the reward: a batch created with
+  ANOTHER seed continues exactly like the original once the checkpoint is
+  loaded; the last control (re-applied by a step without a new action), the
+  episode return and the step count come back too."""
+  n = 48
+  env = suite.load(domain, task, task_kwargs={'random': 3},
+                   environment_kwargs={'batch_size': n})
+  env.reset()
+  rs = np.random.RandomState(1)
+  acts = rs.uniform(-1, 1, (20, n, env.physics.model.nu))
+  for a in acts[:8]:
+    env.step(a)
+  path = str(tmp_path/'state')                      # no extension given
+  env.physics.save_checkpoint(path, step_count=env.step_count)
+  other = suite.load(domain, task, task_kwargs={'random': 99},
+                     environment_kwargs={'batch_size': n})
+  other.reset()
+  assert not np.array_equal(env.physics.batch.read(W.FIELD_TASKDATA),
+                            other.physics.batch.read(W.FIELD_TASKDATA))
+  other.step_count = other.physics.load_checkpoint(path)
+  assert other.step_count == 8
+  for f in (W.FIELD_TASKDATA, W.FIELD_CTRL, W.FIELD_RETURN, W.FIELD_QPOS):
+    np.testing.assert_array_equal(env.physics.batch.read(f),
+                                  other.physics.batch.read(f))
+  # a physics step without a new control re-applies the stored one
+  env.physics.step()
+  other.physics.step()
+  np.testing.assert_array_equal(np.asarray(env.physics.data.qpos),
+                                np.asarray(other.physics.data.qpos))
+  for a in acts[8:]:
+    ts, ts2 = env.step(a), other.step(a)
+  for k in ts.observation:
+    np.testing.assert_array_equal(ts.observation[k], ts2.observation[k])
+  np.testing.assert_array_equal(ts.reward, ts2.reward)
+  np.testing.assert_array_equal(env.physics.batch.read(W.FIELD_RETURN),
+                                other.physics.batch.read(W.FIELD_RETURN))
+  for e in (env, other):
     e.physics.free()
 
 

@@ -1,18 +1,12 @@
 """Sanitizer runs of the kernel SOURCES on the host (no GPU needed).
 
 GPU AddressSanitizer is not available, so csrc/dmc_kernels.hip is compiled as
-plain C++ with -fsanitize=address,undefined (or thread) and stepped next to
-the oracle, before anything touches the card:
-  * tests/host_shim/shim.h: one lane, the per-lane solver (-DDMC_ROWPAR=0, the
-    path of models whose exchange buffer does not fit in LDS);
-  * tests/host_shim/shim_wave.h: one OS thread per lane of a 64-lane workgroup,
-    the row-parallel solver (wave hand-overs are pthread barriers, LDS float
-    atomics take a mutex), incl. partially filled workgroups and a tiny LDS
-    budget so that most row rounds live in the HBM tier.
-This checks the kernel's indexing (static chains, LDS/HBM record tiers, contact
-list, packed row slots) for out-of-bounds, UB and cross-lane races, and its
-arithmetic against the oracle.  The shims are test infrastructure: the product
-path cannot reach them.
+plain C++ through tests/host_shim/shim.h (one lane, one workgroup, fp64) with
+-fsanitize=address,undefined and stepped next to the oracle.  This checks the
+kernel's indexing (static chains, LDS/HBM record tiers, contact list) for
+out-of-bounds and UB, and its arithmetic against the oracle, before anything
+touches the card.  The shim is test infrastructure: the product path cannot
+reach it.
 """
 
 import os
@@ -40,7 +34,7 @@ def _build(model, task, tmp_path, unroll, extra=()):
   exe = tmp_path/'harness'
   cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined',
          '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer',
-         '-DDMC_REAL_IS_DOUBLE', '-DDMC_LDS_BUDGET=16384', '-DDMC_ROWPAR=0'] + list(extra) + [
+         '-DDMC_REAL_IS_DOUBLE', '-DDMC_LDS_BUDGET=16384'] + list(extra) + [
          '-DDMC_MODEL_HEADER="%s"' % header,
          '-DDMC_KERNEL_SOURCE="%s"' % KERNEL,
          '-I', os.path.join(ROOT, 'dm_control_amd', 'csrc'), '-I', SHIM,
@@ -95,88 +89,6 @@ def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path
     np.testing.assert_allclose(state[:model.nq], d.qpos, rtol=0, atol=1e-9)
     np.testing.assert_allclose(state[model.nq:], d.qvel, rtol=0, atol=1e-8)
   assert touched      # constraint rows (LDS and HBM tiers) were exercised
-
-
-# ---------------------------------------------------------------------------
-# row-parallel solver of the one-env-per-lane kernel: one OS thread per lane
-# ---------------------------------------------------------------------------
-def _wave_states(name, nenv):
-  if name == 'cartpole':
-    # carts at / beyond the slider limit (+-1.8) moving outwards: limit rows
-    model, task = helpers.load_model(name), helpers.TASKS[name]
-    q, v = helpers.initial_states(model, name, nenv, seed=7)
-    q[::2, 0] = np.where(np.arange(len(q[::2])) % 2, 1.795, -1.81)
-    v[::2, 0] = np.sign(q[::2, 0])*1.5
-    return model, task, q, v
-  model, task = helpers.load_model(name), helpers.TASKS[name]
-  q, v = helpers.initial_states(model, name, nenv, seed=7)
-  return model, task, q, v
-
-
-@pytest.mark.timeout(1500)
-@pytest.mark.parametrize('name,sanitizer,nenv,steps,lds_budget', [
-    ('cheetah', 'thread', 64, 8, 80000),               # 2 row rounds in LDS, rest in HBM
-    ('cheetah', 'address,undefined', 37, 12, 131072),  # partial workgroup
-    ('hopper', 'address,undefined', 33, 16, 50000),    # touch sensors read packed rows
-    ('cartpole', 'thread', 64, 6, 131072)])            # RK4: four solves per step
-def test_row_parallel_solver_source(name, sanitizer, nenv, steps, lds_budget, tmp_path):
-  model, task, q, v = _wave_states(name, nenv)
-  header = tmp_path/'model.h'
-  text = codegen.generate_header(model, task, unroll=True)
-  header.write_text(text.replace('static __device__ constexpr',
-                                 'static constexpr'))
-  exe = str(tmp_path/'harness_wave')
-  cmd = ['g++', '-std=c++17', '-O1', '-g', '-pthread',
-         '-fsanitize=' + sanitizer, '-fno-omit-frame-pointer',
-         '-DDMC_REAL_IS_DOUBLE', '-DDMC_LDS_BUDGET=%d' % lds_budget,
-         '-DDMC_MODEL_HEADER="%s"' % header,
-         '-DDMC_KERNEL_SOURCE="%s"' % KERNEL,
-         '-I', os.path.join(ROOT, 'dm_control_amd', 'csrc'), '-I', SHIM,
-         '-x', 'c++', os.path.join(SHIM, 'harness_wave.cpp'), '-o', exe]
-  if 'undefined' in sanitizer:
-    cmd.insert(1, '-fno-sanitize-recover=undefined')
-  subprocess.check_call(cmd)
-  args = [exe, str(steps), str(nenv)]
-  for e in range(nenv):
-    args += ['%.17g' % x for x in q[e]] + ['%.17g' % x for x in v[e]]
-  env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0',
-             TSAN_OPTIONS='halt_on_error=1')
-  out = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       universal_newlines=True, env=env, timeout=1400)
-  assert out.returncode == 0, out.stderr[-3000:]
-  lines = out.stdout.splitlines()
-  cfg = dict(kv.split('=') for kv in lines[0].split()[1:])
-  assert cfg['rowpar'] == '1'
-  if lds_budget < 100000:
-    assert int(cfg['glb_rows']) > 0          # the HBM tier is in play
-  om = oracle.OracleModel(model)
-  datas = []
-  for e in range(nenv):
-    d = oracle.OracleData(om)
-    d.qpos[:] = q[e]
-    d.qvel[:] = v[e]
-    d.step1()
-    datas.append(d)
-  seen, rows = 0, 0
-  for line in lines:
-    if not line.startswith('STEP'):
-      continue
-    vals, tail = line.split('|')
-    fields = vals.split()
-    e = int(fields[2])
-    state = np.array([float(x) for x in fields[3:]])
-    ncon, nefc, iters, warn = [int(x) for x in tail.split()]
-    d = datas[e]
-    if model.opt.integrator == 0:     # (RK4: the last of four forward passes)
-      assert (ncon, nefc) == (d.ncon, d.nefc)
-    rows += nefc
-    d.physics_step()
-    assert warn == 0
-    np.testing.assert_allclose(state[:model.nq], d.qpos, rtol=0, atol=1e-9)
-    np.testing.assert_allclose(state[model.nq:], d.qvel, rtol=0, atol=1e-8)
-    seen += 1
-  assert seen == steps*nenv
-  assert rows > 0
 
 
 # ---------------------------------------------------------------------------
