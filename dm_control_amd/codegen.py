@@ -377,10 +377,10 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
       raise UnsupportedModelError('touch sensors need a spherical or box site')
     touch_type.append(kind)
     touch_size += [float(v) for v in m.site_size[sid]]
-    w, x, y, z = [float(v) for v in m.site_quat[sid]]
-    touch_mat += [w*w + x*x - y*y - z*z, 2*(x*y - w*z), 2*(x*z + w*y),
-                  2*(x*y + w*z), w*w - x*x + y*y - z*z, 2*(y*z - w*x),
-                  2*(x*z - w*y), 2*(y*z + w*x), w*w - x*x - y*y + z*z]
+    qw, qx, qy, qz = [float(v) for v in m.site_quat[sid]]
+    touch_mat += [qw*qw + qx*qx - qy*qy - qz*qz, 2*(qx*qy - qw*qz), 2*(qx*qz + qw*qy),
+                  2*(qx*qy + qw*qz), qw*qw - qx*qx + qy*qy - qz*qz, 2*(qy*qz - qw*qx),
+                  2*(qx*qz - qw*qy), 2*(qy*qz + qw*qx), qw*qw - qx*qx - qy*qy + qz*qz]
   ci('NTOUCH', len(touch))
   ti('touch_adr', [int(m.sensor_adr[i]) for i in touch])
   ti('touch_body', [int(m.site_bodyid[int(m.sensor_objid[i])]) for i in touch])

@@ -37,9 +37,10 @@ W = wrapper
 
 
 def _device_batch(model, task, precision, nenv, mode='auto', lds_budget=None,
-                  group=64):
+                  group=64, waves=1):
   hm = W.HipModel(build.build_model(model, task, precision, mode=mode,
-                                    lds_budget=lds_budget, group=group))
+                                    lds_budget=lds_budget, group=group,
+                                    waves=waves))
   return hm, W.HipBatch(hm, nenv)
 
 
@@ -65,10 +66,10 @@ def _degenerate(d, model):
 
 
 def _teacher_forced(name, precision, nenv, steps, nsub, lds_budget=None,
-                    mode=None, group=64):
+                    mode=None, group=64, waves=1):
   model = helpers.load_model(name)
   hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv,
-                         mode or helpers.MODES[name], lds_budget, group)
+                         mode or helpers.MODES[name], lds_budget, group, waves)
   qpos, qvel = helpers.initial_states(model, name, nenv, seed=7)
   om, datas = _oracle_envs(model, qpos, qvel)
   rs = np.random.RandomState(11)
@@ -113,6 +114,8 @@ def test_fp64_build_matches_oracle_per_step(name, nsub):
                                        ('point_mass', 1)])
 def test_fp32_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f32', nenv=128, steps=12, nsub=nsub)
+  print('OBSERVED fp32 per-step %s: median %.2e p99 %.2e max %.2e'
+        % (name, np.median(e), np.percentile(e, 99), e.max()))
   assert np.median(e) <= 2e-6, np.median(e)
   assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
   assert e.max() <= 5e-3, e.max()
@@ -132,8 +135,44 @@ def test_several_lanes_per_env_build_matches_oracle(name, nsub, group):
     assert e.max() <= 1e-9, e.max()
   e = _teacher_forced(name, 'f32', nenv=65, steps=10, nsub=nsub, mode='coop',
                       group=group)
+  print('OBSERVED fp32 per-step coop %s G=%d: median %.2e p99 %.2e max %.2e'
+        % (name, group, np.median(e), np.percentile(e, 99), e.max()))
   assert np.median(e) <= 2e-6, np.median(e)
   assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
+
+
+@pytest.mark.parametrize('name,nsub', [('cheetah', 1), ('walker', 10), ('hopper', 4)])
+def test_four_wavefronts_per_workgroup_match_oracle(name, nsub):
+  """-DDMC_WAVES=4 (what `Physics` picks for the models with contacts up to
+  16384 envs): four wavefronts share a workgroup's 64 envs and split the passes
+  over the constraint rows; partial sums meet behind workgroup barriers.  Odd
+  batch sizes: partially filled last workgroups, whose surplus lanes stay in
+  the kernel for the barriers."""
+  e = _teacher_forced(name, 'f64', nenv=97, steps=10, nsub=nsub, waves=4)
+  assert e.max() <= 1e-9, e.max()
+  e = _teacher_forced(name, 'f32', nenv=130, steps=10, nsub=nsub, waves=4)
+  print('OBSERVED fp32 per-step waves=4 %s: median %.2e p99 %.2e max %.2e'
+        % (name, np.median(e), np.percentile(e, 99), e.max()))
+  assert np.median(e) <= 2e-6, np.median(e)
+  assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
+  # and the same trajectories as the one-wavefront build up to rounding
+  model = helpers.load_model(name)
+  qpos, qvel = helpers.initial_states(model, name, 200, seed=3)
+  ctrl = np.random.RandomState(5).uniform(-1, 1, (8, 200, model.nu))
+  out = []
+  for waves in (1, 4):
+    hm, hb = _device_batch(model, helpers.TASKS[name], 'f64', 200, waves=waves)
+    assert hm.info.lanes_per_env == waves and not hm.info.env_major
+    hb.set_state(qpos.T, qvel.T)
+    for t in range(8):
+      hb.step_host(ctrl[t], nsub)
+    out.append((hb.read(W.FIELD_QPOS), hb.read(W.FIELD_QVEL), hb.read(W.FIELD_OBS),
+                hb.read(W.FIELD_STATS)[:2]))
+    hb.free()
+  np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=1e-9)
+  np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-7)
+  np.testing.assert_allclose(out[0][2], out[1][2], rtol=0, atol=1e-7)
+  np.testing.assert_array_equal(out[0][3], out[1][3])      # same contacts and rows
 
 
 @pytest.mark.parametrize('mode', ['unrolled', 'coop'])
@@ -267,7 +306,7 @@ def test_fp32_cartpole_free_run_1000_steps():
   """BASELINE configs[1]: the smooth system where 1000-step parity is
   meaningful in fp32 (hard part 2)."""
   eq, ev = _free_run('cartpole', 'f32', 256, 1000, 1)
-  print('cartpole fp32 1000-step free run: qpos rel err median %.2e p90 %.2e '
+  print('OBSERVED cartpole fp32 1000-step free run: qpos rel err median %.2e p90 %.2e '
         'max %.2e' % (np.median(eq), np.percentile(eq, 90), eq.max()))
   # random torques drive some poles slowly through the upright (unstable)
   # equilibrium, where any rounding difference is amplified: the bulk of the
@@ -949,7 +988,7 @@ def test_north_star_1000_step_free_run(name):
     for t in range(steps):
       hb.step_host(ctrls[t], 1)
     e = helpers.rel_err(hb.read(W.FIELD_QPOS).T.astype(np.float64), ref)
-    print('%s %s 1000-step free run: median %.2e p90 %.2e max %.2e'
+    print('OBSERVED %s %s 1000-step free run: median %.2e p90 %.2e max %.2e'
           % (name, precision, np.median(e), np.percentile(e, 90), e.max()))
     assert not hb.read(W.FIELD_WARN).any()
     if precision == 'f64':
@@ -1002,7 +1041,7 @@ def test_free_run_trajectories_several_lanes_kernel(name, nsub, steps):
     for t in range(steps):
       hb.step_host(ctrls[t], nsub)
     e = helpers.rel_err(hb.read(W.FIELD_QPOS).T.astype(np.float64), ref)
-    print('%s %s %d-step free run (several lanes per env): median %.2e max %.2e'
+    print('OBSERVED %s %s %d-step free run (several lanes per env): median %.2e max %.2e'
           % (name, precision, steps, np.median(e), e.max()))
     assert not hb.read(W.FIELD_WARN).any()
     if precision == 'f64':
