@@ -268,7 +268,8 @@ def main():
                   help='envs per GPU (weak scaling)')
   ap.add_argument('--global-batch', type=int, default=None,
                   help='total envs, sharded over the GPUs (strong scaling)')
-  ap.add_argument('--precision', default='f32', choices=['f32', 'f64'])
+  ap.add_argument('--precision', default='f32', choices=['f32', 'f64', 'mixed'],
+                  help='mixed: fp32 arithmetic, qpos/qvel carried as fp64 (hi, lo) pairs')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   args = ap.parse_args()
 
@@ -307,7 +308,7 @@ def main():
   info = batch.model.info
   nsub = env._n_sub_steps                      # pylint: disable=protected-access
   step_limit = env._step_limit                 # pylint: disable=protected-access
-  tdtype = torch.float32 if args.precision == 'f32' else torch.float64
+  tdtype = torch.float64 if args.precision == 'f64' else torch.float32
   dev = torch.device('cuda', local_rank)
   gen = torch.Generator(device=dev)
   gen.manual_seed(int(seeds[0]))
@@ -397,7 +398,8 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed/args.steps*1e3, 'higher_is_better': True,
         'scaling': scaling, 'vs_baseline': None,
-        'dtype': args.precision, 'data': 'synthetic',
+        'dtype': {'mixed': 'f32 (state carried in f64)'}.get(args.precision, args.precision),
+        'data': 'synthetic',
         'config': {
             'workload': '%s-%s, %d envs per GPU (dm_control.suite, %d physics '
                         'substeps per env-step%s)'

@@ -156,53 +156,34 @@ def lds_budget_for(nenv):
   return 36*1024            # 4 per CU: one wave on every SIMD
 
 
-def waves_for(model, nenv):
-  """Wavefronts per workgroup of the one-env-per-lane kernel (DMC_WAVES).
-
-  A launch lasts as long as its slowest wavefront, and a wavefront walks as
-  many constraint rows per solver pass as its busiest env has.  While the batch
-  leaves SIMDs idle -- up to 16384 envs = 256 workgroups on 256 CUs -- the four
-  SIMDs of a CU share one workgroup's 64 envs and split the row passes four
-  ways (cheetah-run 8192: see DESIGN.md 5).  Models without contacts have next
-  to no rows and keep one wavefront; so do batches that fill the chip anyway.
-  """
-  if nenv is None or nenv > 16384 or model.nv == 0:
-    return 1
-  if not codegen.collision_pairs(model):
-    return 1
-  return 4
-
-
 def build_model(model, task=codegen.TASK_NONE, precision='f32',
                 ncon_max=None, force=False, keep_temps=False, extra_flags=None,
-                mode='auto', lds_budget=None, group=64, waves=1):
+                mode='auto', lds_budget=None, group=64):
   """Generates the constants header for `model` and compiles its kernels.
 
   mode: "unrolled" (static indexing, per-lane state in registers), "rolled"
   (generic loops, per-lane arrays in scratch) or "auto" (unrolled unless its
   register spills exceed MAX_*_SPILLS), or "coop": `group` lanes advance one
   env together with its working set in LDS (csrc/dmc_coop.hip; the shape for
-  nv ~ 20+ models and for small shards).  waves > 1 (one-env-per-lane modes):
-  that many wavefronts per workgroup share its 64 envs and split the passes
-  over the constraint rows -- for batches that leave SIMDs idle.  Returns the
-  path of the gfx950 code object; cached in-tree by content hash.
+  nv ~ 20+ models and for small shards).  Returns the path of the gfx950 code
+  object; cached in-tree by content hash.
   """
-  if precision not in ('f32', 'f64'):
-    raise ValueError('precision must be "f32" or "f64"')
+  if precision not in ('f32', 'f64', 'mixed'):
+    raise ValueError('precision must be "f32", "f64" or "mixed"')
   if mode not in ('auto', 'unrolled', 'rolled', 'coop'):
     raise ValueError('mode must be auto, unrolled, rolled or coop')
   if extra_flags is None:
     # experiment hook: extra -D flags for ablation builds (never set in tests)
     extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
+  if precision == 'mixed':
+    # fp32 arithmetic, qpos/qvel carried between steps as fp64 (high, low)
+    # pairs (csrc/dmc_kernels.hip, DMC_STATE_COMP); one-env-per-lane kernel only
+    if mode == 'coop':
+      raise ValueError('precision "mixed" is built for the one-env-per-lane kernel')
+    precision = 'f32'
+    extra_flags = tuple(extra_flags) + ('-DDMC_STATE_COMP=1',)
   if lds_budget is not None and lds_budget != 128*1024:
     extra_flags = tuple(extra_flags) + ('-DDMC_LDS_BUDGET=%d' % lds_budget,)
-  if waves not in (1, 2, 4):
-    raise ValueError('waves (wavefronts per workgroup) must be 1, 2 or 4')
-  if waves != 1 and mode != 'coop':
-    # the exchange buffers of the split solver come on top of the row store
-    extra_flags = tuple(extra_flags) + ('-DDMC_WAVES=%d' % waves,)
-    if lds_budget is None:
-      extra_flags += ('-DDMC_LDS_BUDGET=%d' % (156*1024),)
   os.makedirs(_BUILD, exist_ok=True)
   if mode == 'coop':
     # several lanes per env (csrc/dmc_coop.hip): working set in LDS, generic

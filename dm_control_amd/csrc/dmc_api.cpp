@@ -51,7 +51,6 @@ struct dmc_model {
   int device = 0;
   hipModule_t module = nullptr;
   hipFunction_t k_step = nullptr, k_observe = nullptr, k_init = nullptr;
-  int threads_per_block = 64;   // workgroup size of the step / observe kernels
   dmc_model_info info{};
 };
 
@@ -82,16 +81,13 @@ int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args, int group = -1) {
   size_t size = sizeof(DmcArgs);
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args,
                     HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  // The code object reports the shape of its step / observe kernels in dmc_info:
-  // threads per workgroup and envs per workgroup (one env per lane of a single
-  // wavefront; several wavefronts sharing 64 envs; or a group of lanes per env).
-  // `group` < 0: the task-setup kernel, always one env per lane of a full wave.
+  // Workgroup = one wavefront.  `group` lanes advance one env together (the
+  // code object reports its shape in dmc_info); `group` < 0: the task-setup
+  // kernel, always one env per lane of a full wave.
   const dmc_model_info& mi = b->model->info;
   unsigned block = 64, per_block = 64;
-  if (group >= 1) {
-    block = (unsigned)b->model->threads_per_block;
-    per_block = (unsigned)mi.envs_per_block;
-  }
+  if (group > 1) { per_block = (unsigned)mi.envs_per_block; }
+  else if (group == 1) { block = per_block = (unsigned)mi.envs_per_block; }
   const unsigned grid = (unsigned)((b->nenv + per_block - 1)/per_block);
   HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, b->stream,
                                 nullptr, config));
@@ -198,7 +194,6 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   // raw[14] envs per workgroup, raw[17] threads per workgroup: one env per lane
   // (64, 32 or 16 envs in a 64-wide wave) or a group of lanes per env
   i.envs_per_block = raw[14] > 0 ? raw[14] : 64;
-  m->threads_per_block = raw[17] > 0 ? raw[17] : 64;
   i.lanes_per_env = raw[17] > i.envs_per_block ? raw[17]/i.envs_per_block : 1;
   i.env_major = raw[15] != 0;
   i.ntaskdata = raw[16];

@@ -51,7 +51,11 @@ constexpr int NOBSX = NOBS > 0 ? NOBS : 1;
 constexpr int NSDX = NSENSORDATA > 0 ? NSENSORDATA : 1;
 constexpr int NVP = odd_(NVX);          // row stride of M and H (odd: lane = row is conflict-free)
 // constraint row record: J(nv), D, aref, Jaref, Jv, force
-enum { CR_D = NV, CR_AREF = NV + 1, CR_JAR = NV + 2, CR_JV = NV + 3, CR_F = NV + 4 };
+enum { CR_D = NV, CR_AREF = NV + 1, CR_JAR = NV + 2, CR_JV = NV + 3, CR_F = NV + 4,
+       // the reference acceleration is dead once the warm start has been rated:
+       // its word then carries the row's pending Hessian change (+1 enters the
+       // active set, -1 leaves it, 0 stays)
+       CR_FLIP = CR_AREF };
 constexpr int CRW = odd_(NV + 5);
 // contact record: pos(3) normal(3) tangent hint(3) dist pair first-row
 enum { CC_DIST = 9, CC_PAIR = 10, CC_ROW = 11 };
@@ -1023,6 +1027,11 @@ struct Coop {
     P.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
   }
 
+  // As in dmc_kernels.hip: the Hessian M + J^T D_active J is kept across the
+  // iterations and only the rows that changed sides are added or removed, and
+  // (fp32) the pass that computes Jv also evaluates the line-search point
+  // alpha = 1, the exact Newton step, so the usual iteration needs no further
+  // line-search pass.
   __device__ void solve_newton(real tol) {
     const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
     for (int i = l; i < NV; i += G) S[off::MA + i] = mrow_dot(i, off::QACC);
@@ -1030,38 +1039,50 @@ struct Coop {
     real improvement = 0;
     bool converged = false;
     int iter = 0;
+    Rows H;
+    rows_load(H, off::MM);
     for (;; iter++) {
-      // constraint forces of the active rows (lane = row)
+      // constraint forces of the active rows (lane = row); the first iteration
+      // adds every active row to H
       for (int r = l; r < nefc; r += G) {
         real* row = S + off::ROWS + r*CRW;
         const real jar = row[CR_JAR];
         row[CR_F] = jar < 0 ? -row[CR_D]*jar : R(0);
+        if (iter == 0) row[CR_FLIP] = jar < 0 ? R(1) : R(0);
       }
       gsync();
-      // lane = dof: qfrc_constraint, gradient and row i of H = M + J^T D J
+      // lane = dof: qfrc_constraint, gradient, changes of row i of H
       real gn = 0;
-      Rows H;
       real grad[RNV];
       {
         real fc[RNV];
-        rows_load(H, off::MM);
         _Pragma("unroll")
         for (int t = 0; t < RNV; t++) fc[t] = 0;
         for (int r = 0; r < nefc; r++) {
           const real* row = S + off::ROWS + r*CRW;
-          if (!(row[CR_JAR] < 0)) continue;
-          const real D = row[CR_D], f = row[CR_F];
-          real jr[NVX];
-          _Pragma("unroll")
-          for (int k = 0; k < NV; k++) jr[k] = row[k];
-          _Pragma("unroll")
-          for (int t = 0; t < RNV; t++) {
-            const int i = l + t*G;
-            const real ji = i < NV ? row[i] : R(0);
-            fc[t] += ji*f;
-            const real s = D*ji;
+          const real flip = row[CR_FLIP];
+          if (!(row[CR_JAR] < 0) && flip == 0) continue;
+          const real f = row[CR_F];
+          if (flip != 0) {
+            const real D = flip*row[CR_D];
+            real jr[NVX];
             _Pragma("unroll")
-            for (int k = 0; k < NV; k++) H.a[t][k] += s*jr[k];
+            for (int k = 0; k < NV; k++) jr[k] = row[k];
+            _Pragma("unroll")
+            for (int t = 0; t < RNV; t++) {
+              const int i = l + t*G;
+              const real ji = i < NV ? row[i] : R(0);
+              fc[t] += ji*f;
+              const real s = D*ji;
+              _Pragma("unroll")
+              for (int k = 0; k < NV; k++) H.a[t][k] += s*jr[k];
+            }
+          } else {
+            _Pragma("unroll")
+            for (int t = 0; t < RNV; t++) {
+              const int i = l + t*G;
+              fc[t] += (i < NV ? row[i] : R(0))*f;
+            }
           }
         }
         _Pragma("unroll")
@@ -1080,11 +1101,12 @@ struct Coop {
       PROF(PH_HESS);
       if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
       if (iter >= ITERATIONS) break;
-      rows_chol(H, off::HH);
+      Rows F = H;                       // the factorisation works in place
+      rows_chol(F, off::HH);
       PROF(PH_FACH);
       _Pragma("unroll")
       for (int t = 0; t < RNV; t++) grad[t] = -grad[t];
-      rows_solve(H, off::HH, grad);
+      rows_solve(F, off::HH, grad);
       _Pragma("unroll")
       for (int t = 0; t < RNV; t++) if (l + t*G < NV) S[off::SEARCH + l + t*G] = grad[t];
       gsync();
@@ -1101,24 +1123,43 @@ struct Coop {
       sn = sqrt(gsum(sn)); q1 = gsum(q1); q2 = gsum(q2);
       if (sn < DMC_MINVAL) break;
       const real gtol = tol*R(0.01)*sn/scale;
-      for (int r = l; r < nefc; r += G) {
-        real* row = S + off::ROWS + r*CRW;
-        real sacc = 0;
-        _Pragma("unroll")
-        for (int j = 0; j < NV; j++) sacc += row[j]*S[off::SEARCH + j];
-        row[CR_JV] = sacc;
+      // Jv, the line-search derivatives at alpha = 0 and (fp32) the point alpha = 1
+      Ls p0, p, best;
+      {
+        real d0 = 0, d1 = 0, c1 = 0, e0 = 0, e1 = 0;
+        for (int r = l; r < nefc; r += G) {
+          real* row = S + off::ROWS + r*CRW;
+          real sacc = 0;
+          _Pragma("unroll")
+          for (int j = 0; j < NV; j++) sacc += row[j]*S[off::SEARCH + j];
+          row[CR_JV] = sacc;
+          const real x0 = row[CR_JAR], Dv = row[CR_D]*sacc;
+          if (x0 < 0) { d0 += Dv*x0; d1 += Dv*sacc; }
+          if (DMC_F32_RULES) {
+            const real x = x0 + sacc;
+            const real xa = x < 0 ? x : R(0), xa0 = x0 < 0 ? x0 : R(0);
+            c1 += R(0.5)*row[CR_D]*(xa*xa - xa0*xa0);
+            if (x < 0) { e0 += Dv*x; e1 += Dv*sacc; }
+          }
+        }
+        d0 = gsum(d0) + q1; d1 = gsum(d1) + 2*q2;
+        p0.alpha = 0; p0.dcost = 0; p0.d0 = d0;
+        p0.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+        if (DMC_F32_RULES) {
+          c1 = gsum(c1) + q2 + q1; e0 = gsum(e0) + 2*q2 + q1; e1 = gsum(e1) + 2*q2;
+          p.alpha = 1; p.dcost = c1; p.d0 = e0;
+          p.d1 = e1 > DMC_MINVAL ? e1 : DMC_MINVAL;
+        }
       }
       gsync();
       // exact line search: safeguarded Newton on the directional derivative
-      Ls p0, p, best;
-      ls_eval(p0, 0, q1, q2);
       if (!(p0.d0 < 0)) break;
       best = p0;
-      real lo = 0, hi = 0, a = -p0.d0/p0.d1;
+      real lo = 0, hi = 0, a = DMC_F32_RULES ? R(1) : -p0.d0/p0.d1;
       bool have_hi = false;
       const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
       for (int it = 0; it < DMC_LS_MAXIT; it++) {
-        ls_eval(p, a, q1, q2);
+        if (!(DMC_F32_RULES && it == 0)) ls_eval(p, a, q1, q2);
         if (p.dcost < best.dcost) best = p;
         if (fabs(p.d0) < dtol) break;
         if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
@@ -1144,8 +1185,10 @@ struct Coop {
         real* row = S + off::ROWS + r*CRW;
         const real x0 = row[CR_JAR];
         const real x1 = x0 + alpha*row[CR_JV];
-        changed |= (x0 < 0) != (x1 < 0);
+        const real flip = R((x1 < 0) - (x0 < 0));
+        changed |= flip != 0;
         row[CR_JAR] = x1;
+        row[CR_FLIP] = flip;
       }
       changed = gany(changed);
       gsync();
@@ -1528,12 +1571,19 @@ dmc_observe(DmcArgs a) {
   C.load(a, e);
   for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[sidx(i, e, n, NUX)];
   gsync();
-  if (NTOUCH > 0 && !(a.flags & 4)) {   // mj_forward, actuation disabled (after_reset)
+  if (NTOUCH > 0) {
+    // acceleration-stage sensors need the constraint forces: the reference's
+    // after_reset runs mj_forward with actuation disabled (engine.py:283-295);
+    // a bad state is reset first (mj_checkPos), as mj_forward would see it
     const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
-    if (!C.check_state()) C.forward(false, tol);
+    C.check_state();
+    C.forward(false, tol);
   }
+  const int ncon_forward = C.ncon, nefc_forward = C.nefc;
   C.observe_stage();
-  if (a.flags & 4) {   // count contacts only (humanoid reset rejection test)
+  if (NTOUCH > 0) {
+    C.ncon = ncon_forward; C.nefc = nefc_forward;
+  } else if (a.flags & 4) {   // count contacts (humanoid reset rejection test)
     C.ncon = 0; C.nefc = 0;
     if (NPAIR > 0) C.detect_contacts();
   }

@@ -74,21 +74,7 @@ using namespace dmc_model;
 #define DEVN static __device__ __forceinline__
 
 constexpr int NM = NV*(NV + 1)/2;      // packed lower triangle
-constexpr int LANES = 64;               // envs per workgroup = lanes of a wavefront
-// Wavefronts per workgroup (-DDMC_WAVES=4).  While the batch leaves SIMDs idle
-// (8192 envs = 128 workgroups on 256 CUs x 4 SIMDs) the four SIMDs of a CU can
-// work on the same 64 envs: every wave carries the whole per-env state (the
-// tree passes are replicated, they cost no wall time on an idle SIMD) and the
-// passes over the constraint rows -- what bounds the launch: a wave walks as
-// many rows as its busiest env has -- are split, wave w taking rows r = w mod
-// NW and the contacts k = w mod NW of the row builder.  Per-env partial sums
-// meet in LDS behind a workgroup barrier and are added in a fixed order, so
-// all waves continue with bit-identical values and identical control flow.
-#ifndef DMC_WAVES
-#define DMC_WAVES 1
-#endif
-constexpr int NW = DMC_WAVES;
-static_assert(NW == 1 || NW == 2 || NW == 4, "wavefronts per workgroup");
+constexpr int LANES = 64;               // envs per workgroup = one wavefront
 constexpr int MAT_REGS = NM > 0 ? NM : 1;
 constexpr int NVX = NV > 0 ? NV : 1;
 constexpr int NUX = NU > 0 ? NU : 1;
@@ -346,14 +332,7 @@ constexpr int CW = 11;
 #define DMC_CON_LDS 12
 #endif
 constexpr int REC_BYTES = LANES*(int)sizeof(real);    // one record word, all lanes
-// exchange buffers of the split solver passes, [wave][word][lane]: one large
-// (Hessian terms + constraint force + active-set changes) and two small ones
-// used alternately (line-search and warm-start sums)
-constexpr int XA_WORDS = NW > 1 ? NM + NV : 0;
-constexpr int XS_WORDS = NW > 1 ? 5 : 0;
-constexpr int X_WORDS = NW*(XA_WORDS + 2*XS_WORDS);
-constexpr int REC_BUDGET = DMC_LDS_BUDGET - X_WORDS*REC_BYTES;
-static_assert(REC_BUDGET > 0, "LDS budget too small for the exchange buffers");
+constexpr int REC_BUDGET = DMC_LDS_BUDGET;
 constexpr int LDS_CONS_WANT = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
 constexpr int LDS_CONS_FIT = (REC_BUDGET/2)/(CW*REC_BYTES);   // <= half the budget
 constexpr int LDS_CONS = LDS_CONS_WANT < LDS_CONS_FIT ? LDS_CONS_WANT : LDS_CONS_FIT;
@@ -364,7 +343,6 @@ constexpr int GLB_ROWS = NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 0;
 constexpr int GLB_CONS = NCON_MAX - LDS_CONS > 0 ? NCON_MAX - LDS_CONS : 0;
 enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3 };
 
-constexpr int LDS_ROWS_ = LDS_ROWS, RW_ = RW, LDS_CONS_ = LDS_CONS, CW_ = CW;
 struct LdsRow {
   real* p;
   __device__ __forceinline__ real get(int k) const { return p[k*LANES]; }
@@ -389,37 +367,21 @@ constexpr int WS_WORDS = WS_COMP;
 #endif
 
 struct Work {
-  real* lds;   // LDS base + lane (rows, contact records, then exchange buffers)
+  real* lds;   // LDS base + lane (rows, then contact records)
   real* glb;   // workspace base + env
   long long nenv;
-  int wave;    // this wavefront's index in the workgroup (0 when NW == 1)
-  int phase;   // which small exchange buffer is next
-  // Exchange buffers: at the START of the workgroup's LDS, so that every word
-  // is reached from `lds` with the 16-bit immediate offset of a DS instruction
-  // (cheetah, NW = 4: 2*4*5 + 4*54 words of 256 B = exactly 64 KB).  Placed
-  // behind the row store they cost one address register per word, hoisted out
-  // of the solver loop: measured 650 live registers, 138 spilled, 5x slower.
-  __device__ __forceinline__ real* xs(int buf, int w, int k) const {
-    return lds + ((buf*NW + w)*XS_WORDS + k)*LANES;
-  }
-  __device__ __forceinline__ real* xa(int w, int k) const {
-    return lds + (2*NW*XS_WORDS + w*XA_WORDS + k)*LANES;
-  }
-  __device__ __forceinline__ LdsRow lrow(int r) const {
-    return LdsRow{lds + (X_WORDS + r*RW)*LANES};
-  }
+  __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*LANES}; }
   __device__ __forceinline__ GlbRow grow(int r) const {
     return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
   }
   __device__ __forceinline__ LdsRow lcon(int k) const {
-    return LdsRow{lds + (X_WORDS + LDS_ROWS*RW + k*CW)*LANES};
+    return LdsRow{lds + (LDS_ROWS*RW + k*CW)*LANES};
   }
   __device__ __forceinline__ GlbRow gcon(int k) const {
     return GlbRow{glb + ((long long)GLB_ROWS*RW + (long long)(k - LDS_CONS)*CW)*nenv, nenv};
   }
 };
-constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW + X_WORDS > 0
-                           ? LDS_ROWS*RW + LDS_CONS*CW + X_WORDS : 1)*LANES;
+constexpr int LDS_WORDS = (LDS_ROWS*RW + LDS_CONS*CW > 0 ? LDS_ROWS*RW + LDS_CONS*CW : 1)*LANES;
 // f(row handle) for rows [0, nefc): LDS tier first, then the HBM tier
 template <class F>
 static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) {
@@ -427,13 +389,6 @@ static __device__ __forceinline__ void for_rows(const Work& W, int nefc, F&& f) 
   for (int r = 0; r < n1; r++) f(W.lrow(r));
   if (LDS_ROWS < NEFC_MAX)
     for (int r = LDS_ROWS; r < nefc; r++) f(W.grow(r));
-}
-// f(row handle) for this wavefront's share of the rows: r = wave mod NW
-template <class F>
-static __device__ __forceinline__ void for_my_rows(const Work& W, int nefc, F&& f) {
-  for (int r = W.wave; r < nefc; r += NW) {
-    if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS) f(W.lrow(r)); else f(W.grow(r));
-  }
 }
 // The same in two stages: `load(row handle)` returns the words a row needs,
 // `use(words)` consumes them; the words of row r + 1 are requested before row r
@@ -878,13 +833,10 @@ DEV void write_row(const Row& rec, const Env& E, const real* row, real pm,
   rec.set(ROW_AREF, -B*vel - K*imp*pm);
   rec.set(ROW_D, R(1)/(Rrow < DMC_MINVAL ? DMC_MINVAL : Rrow));
 }
-// `write` false: only reserves the row (its record is written by the wavefront
-// that builds it, see NW)
 DEV bool push_row(Env& E, const Work& W, const real* row, real pos_minus_margin,
-                  real K, real B, real imp, real Rrow, bool write = true) {
+                  real K, real B, real imp, real Rrow) {
   if (E.nefc >= NEFC_MAX) { E.warn |= WARN_CNSTRFULL; return false; }
   const int r = E.nefc++;
-  if (!write) return true;
   if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS)
     write_row(W.lrow(r), E, row, pos_minus_margin, K, B, imp, Rrow);
   else
@@ -910,8 +862,7 @@ DEV void limit_rows(Env& E, const Work& W) {
         const real pm = dist - margin;
         const real imp = impedance(limit_solimp + 5*l, pm);
         const real Rr = (1 - imp)*R(dof_invweight0[dof])/imp;
-        push_row(E, W, row, pm, R(limit_K[l]), R(limit_B[l]), imp, Rr,
-                 NW == 1 || (2*l + (side > 0)) % NW == W.wave);
+        push_row(E, W, row, pm, R(limit_K[l]), R(limit_B[l]), imp, Rr);
       }
     }
   }
@@ -1140,7 +1091,6 @@ DEV void detect_contacts(Env& E, const Work& W) {
       if (!((mask >> c) & 1)) continue;
       if (E.ncon >= NCON_MAX) { E.warn |= WARN_CONTACTFULL; continue; }
       const int k = E.ncon++;
-      if (NW > 1 && W.wave != 0) continue;      // every wave counts, one writes
       if (LDS_CONS >= NCON_MAX || k < LDS_CONS) write_contact(W.lcon(k), p, rc[c]);
       else write_contact(W.gcon(k), p, rc[c]);
     }
@@ -1153,16 +1103,11 @@ DEV void detect_contacts(Env& E, const Work& W) {
 // masks over the statically indexed cdof registers (no dynamic indexing of
 // per-lane state).
 template <class Rec>
-DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec, bool mine) {
+DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
   const int p = (int)rec.get(10);
   const real dist = rec.get(9);
   const real includemargin = pair_includemargin[p];
   if (dist >= includemargin) return;
-  if (!mine) {   // another wavefront builds this contact's rows: reserve them
-    const int nrow = pair_nrow[p];
-    for (int j = 0; j < nrow; j++) push_row(E, W, nullptr, 0, 0, 0, 0, 0, false);
-    return;
-  }
   real pos[3], fin[6], f[9];
   DMC_UNROLL
   for (int k = 0; k < 3; k++) { pos[k] = rec.get(k); fin[k] = rec.get(3 + k); fin[3 + k] = rec.get(6 + k); }
@@ -1251,12 +1196,10 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec, bool mine) {
 
 DEV void contact_rows(Env& E, const Work& W) {
   detect_contacts(E, W);
-  if (NW > 1) __syncthreads();     // the contact list is written by wave 0
   const int n1 = E.ncon < LDS_CONS ? E.ncon : LDS_CONS;
-  for (int k = 0; k < n1; k++) rows_of_contact(E, W, W.lcon(k), k % NW == W.wave);
+  for (int k = 0; k < n1; k++) rows_of_contact(E, W, W.lcon(k));
   if (LDS_CONS < NCON_MAX)
-    for (int k = LDS_CONS; k < E.ncon; k++)
-      rows_of_contact(E, W, W.gcon(k), k % NW == W.wave);
+    for (int k = LDS_CONS; k < E.ncon; k++) rows_of_contact(E, W, W.gcon(k));
 }
 
 // ---------------------------------------------------------------------------
@@ -1453,274 +1396,6 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
 }
 
 // ---------------------------------------------------------------------------
-// The same solver for NW > 1 wavefronts per workgroup: every wave holds the
-// whole per-env state and runs the env-indexed parts (Cholesky, line-search
-// logic, stopping rules) redundantly; each pass over the rows covers only the
-// wave's share (rows r = wave mod NW), and the per-env partial sums are
-// exchanged through LDS behind a workgroup barrier and added in wave order, so
-// that all waves hold bit-identical values.  Barriers sit in loops that are
-// uniform over the wavefront (`wany`): lanes whose env has finished stay in
-// the loop with `active` cleared, which keeps the barrier count of the four
-// waves equal (they see identical data, hence identical control flow).
-// ---------------------------------------------------------------------------
-#ifndef DMC_HOST_SHIM
-#define DMC_SCHED_STOP() __builtin_amdgcn_sched_barrier(0)
-DEV bool wany(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
-// lanes of ONE wavefront hand LDS data over (the LDS queue is in order within a
-// wave; the fences pin the compiler and drain the counters)
-DEV void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-#endif
-
-#ifdef DMC_HOST_SHIM
-#define DMC_SCHED_STOP() do {} while (0)
-#endif
-// sums v[0..N) over the wavefronts of the workgroup (small, double-buffered:
-// a wave can be at most one exchange ahead of the slowest one)
-template <int N>
-DEV void xsum(Work& W, real* v) {
-  static_assert(N <= XS_WORDS || NW == 1, "small exchange buffer");
-  if (NW == 1) return;
-  const int buf = W.phase & 1;
-  W.phase++;
-  DMC_UNROLL
-  for (int k = 0; k < N; k++) *W.xs(buf, W.wave, k) = v[k];
-  __syncthreads();
-  DMC_UNROLL
-  for (int k = 0; k < N; k++) {
-    real t = 0;
-    DMC_UNROLL
-    for (int w = 0; w < NW; w++) t += *W.xs(buf, w, k);
-    v[k] = t;
-  }
-}
-
-DEV void solve_newton_split(Env& E, Work& W, real tol, bool active, bool start_smooth) {
-#ifdef DMC_SOLVER_PROFILE
-  long long tl_ = wall_clock64();
-#endif
-  real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], Hreg[MAT_REGS];
-  const auto M = Mats::M(E, W);
-  const RegMat H{Hreg};
-  const RegMat F = Mats::L(E, W);
-  const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
-  const int nefc = active ? E.nefc : 0;
-  symv(Ma, M, E.qacc);
-  DMC_UNROLL
-  for (int i = 0; i < NM; i++) H.set(i, M.get(i));
-  DMC_UNROLL
-  for (int i = 0; i < NV; i++) { Mv[i] = 0; search[i] = 0; }
-  real improvement = 0, alpha_prev = 0;
-  for (int iter = 0;; iter++) {     // the same `iter` for every env still active
-    // pass A over this wave's rows: apply the previous step to Jaref, note
-    // active-set changes, partial constraint force and Hessian changes
-    // (the Hessian changes are gathered in the factor's registers, dead here)
-    real fpart[NVX];
-    DMC_UNROLL
-    for (int i = 0; i < NM; i++) F.set(i, 0);
-    DMC_UNROLL
-    for (int i = 0; i < NV; i++) fpart[i] = 0;
-    real nchanged = 0;
-    if (active) for_my_rows(W, nefc, [&](auto rec) {
-      real jar = rec.get(ROW_JAR);
-      const real jv = rec.get(ROW_JV), D = rec.get(ROW_D);
-      real row[NVX];
-      DMC_UNROLL
-      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
-      bool was = false;
-      if (iter > 0) {
-        was = jar < 0;
-        jar += alpha_prev*jv;
-        rec.set(ROW_JAR, jar);
-      } else if (start_smooth) {
-        jar = jv;
-        rec.set(ROW_JAR, jar);
-      }
-      const bool now = jar < 0;
-      if (now) {
-        const real f = -D*jar;
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) fpart[j] += row[j]*f;
-      }
-      if (now != was) {
-        nchanged += 1;
-        const real Ds = now ? D : -D;
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) {
-          const real s = Ds*row[j];
-          DMC_UNROLL
-          for (int k = 0; k <= j; k++) F.set(tri(j, k), F.get(tri(j, k)) + s*row[k]);
-        }
-      }
-    });
-    // exchange: [dH, force, changes] of the NW waves.  The buffer is free
-    // again: every wave read the previous iteration's sums before it reached
-    // the barrier of that iteration's pass B.
-    DMC_UNROLL
-    for (int i = 0; i < NM; i++) *W.xa(W.wave, i) = F.get(i);
-    DMC_UNROLL
-    for (int i = 0; i < NV; i++) *W.xa(W.wave, NM + i) = fpart[i];
-    const int xbuf = W.phase & 1;      // the change count rides in a small buffer
-    W.phase++;
-    *W.xs(xbuf, W.wave, 0) = nchanged;
-    __syncthreads();
-    real nch = 0;
-    if (active) {     // (an env that has finished keeps its force and Hessian)
-      DMC_UNROLL
-      for (int i = 0; i < NM; i++) {
-        real t = 0;
-        DMC_UNROLL
-        for (int w = 0; w < NW; w++) t += *W.xa(w, i);
-        H.set(i, H.get(i) + t);
-        // keep the scheduler from hoisting all NW*NM loads (and their registers)
-        if (i % 8 == 7) DMC_SCHED_STOP();
-      }
-      DMC_UNROLL
-      for (int w = 0; w < NW; w++) nch += *W.xs(xbuf, w, 0);
-      DMC_UNROLL
-      for (int i = 0; i < NV; i++) {
-        real t = 0;
-        DMC_UNROLL
-        for (int w = 0; w < NW; w++) t += *W.xa(w, NM + i);
-        E.qfrc_constraint[i] = t;
-      }
-    }
-    SPROF(0);
-    real q1 = 0, q2 = 0, gtol = 0;
-    if (active) {
-      const bool changed = nch != 0;
-      const bool converged = DMC_F32_RULES && iter > 0 && !changed &&
-                             fabs(alpha_prev - 1) < R(1e-3);
-      real gn = 0;
-      DMC_UNROLL
-      for (int i = 0; i < NV; i++) {
-        grad[i] = Ma[i] - E.qfrc_smooth[i] - E.qfrc_constraint[i];
-        gn += grad[i]*grad[i];
-      }
-      if ((iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) ||
-          iter >= ITERATIONS) {
-        active = false; E.iters = iter;
-      } else {
-        DMC_UNROLL
-        for (int i = 0; i < NM; i++) F.set(i, H.get(i));
-        chol_factor(F);
-        DMC_UNROLL
-        for (int i = 0; i < NV; i++) search[i] = -grad[i];
-        chol_solve(search, F);
-        real sn = 0;
-        DMC_UNROLL
-        for (int i = 0; i < NV; i++) sn += search[i]*search[i];
-        sn = sqrt(sn);
-        alpha_prev = 0;
-        if (sn < DMC_MINVAL) {
-          active = false; E.iters = iter;
-        } else {
-          gtol = tol*R(0.01)*sn/scale;
-          symv(Mv, M, search);
-          DMC_UNROLL
-          for (int i = 0; i < NV; i++) {
-            q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
-            q2 += R(0.5)*search[i]*Mv[i];
-          }
-        }
-      }
-    }
-    SPROF(1);
-    if (!wany(active)) break;
-    // pass B: Jv, derivatives along `search` at alpha = 0 and (fp32) the point alpha = 1
-    real sums[5] = {0, 0, 0, 0, 0};       // d0, d1 at 0; dcost, d0, d1 at 1
-    if (active) for_my_rows(W, nefc, [&](auto rec) {
-      real row[NVX];
-      DMC_UNROLL
-      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
-      const real x0 = rec.get(ROW_JAR), D = rec.get(ROW_D);
-      real sacc = 0;
-      DMC_UNROLL
-      for (int j = 0; j < NV; j++) sacc += row[j]*search[j];
-      rec.set(ROW_JV, sacc);
-      const real Dv = D*sacc;
-      if (x0 < 0) { sums[0] += Dv*x0; sums[1] += Dv*sacc; }
-      if (DMC_F32_RULES) {
-        const real x = x0 + sacc;
-        const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
-        sums[2] += R(0.5)*D*(a*a - a0*a0);
-        if (x < 0) { sums[3] += Dv*x; sums[4] += Dv*sacc; }
-      }
-    });
-    xsum<5>(W, sums);
-    SPROF(2);
-    LsPoint p0, p, best;
-    p0.alpha = 0; p0.dcost = 0; p0.d0 = q1 + sums[0];
-    p0.d1 = 2*q2 + sums[1] > DMC_MINVAL ? 2*q2 + sums[1] : DMC_MINVAL;
-    p.alpha = 1; p.dcost = q2 + q1 + sums[2]; p.d0 = 2*q2 + q1 + sums[3];
-    p.d1 = 2*q2 + sums[4] > DMC_MINVAL ? 2*q2 + sums[4] : DMC_MINVAL;
-    best = p0;
-    real lo = 0, hi = 0, a = DMC_F32_RULES ? R(1) : -p0.d0/p0.d1, dtol = 0;
-    bool have_hi = false, ls = false;
-    if (active) {
-      if (!(p0.d0 < 0)) {
-        active = false; E.iters = iter;
-      } else {
-        dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
-        ls = true;
-      }
-    }
-    // exact line search, every env with its own bracket; one (split) pass over
-    // the rows and one exchange per evaluation
-    for (int it = 0; it < DMC_LS_MAXIT; it++) {
-      if (!(DMC_F32_RULES && it == 0)) {
-        if (!wany(ls)) break;
-        real e[3] = {0, 0, 0};
-        if (ls) for_my_rows(W, nefc, [&](auto rec) {
-          const real x0 = rec.get(ROW_JAR), v = rec.get(ROW_JV), D = rec.get(ROW_D);
-          const real x = x0 + a*v;
-          const real xa = x < 0 ? x : R(0), xa0 = x0 < 0 ? x0 : R(0);
-          e[0] += R(0.5)*D*(xa*xa - xa0*xa0);
-          if (x < 0) { e[1] += D*x*v; e[2] += D*v*v; }
-        });
-        xsum<3>(W, e);
-        SCOUNT(5);
-        p.alpha = a; p.dcost = a*a*q2 + a*q1 + e[0]; p.d0 = 2*a*q2 + q1 + e[1];
-        p.d1 = 2*q2 + e[2] > DMC_MINVAL ? 2*q2 + e[2] : DMC_MINVAL;
-      }
-      if (ls) {
-        if (p.dcost < best.dcost) best = p;
-        if (fabs(p.d0) < dtol) {
-          ls = false;
-        } else {
-          if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
-          real an = a - p.d0/p.d1;
-          if (have_hi) {
-            if (!(an > lo && an < hi)) an = R(0.5)*(lo + hi);
-            if (hi - lo < R(1e-6)*hi) ls = false;
-          } else if (an <= lo) {
-            an = 2*a;
-          }
-          if (ls) a = an;
-        }
-      }
-    }
-    SPROF(3);
-    if (active) {
-      const real alpha = best.alpha;
-      if (alpha == 0) {
-        active = false; E.iters = iter;
-      } else {
-        improvement = -best.dcost;
-        DMC_UNROLL
-        for (int i = 0; i < NV; i++) { E.qacc[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
-        alpha_prev = alpha;
-      }
-    }
-    SPROF(4);
-    if (!wany(active)) break;
-  }
-}
-
-// ---------------------------------------------------------------------------
 // touch sensors (mjSENS_TOUCH in mj_sensorAcc): sum of the normal forces of the
 // contacts that involve the sensor site's body and whose force ray, cast from
 // the contact point, meets the site's spherical zone
@@ -1821,10 +1496,8 @@ DEV void touch_sensors(Env& E, const Work& W) {
     for (int k = LDS_CONS; k < E.ncon; k++) touch_of_contact(E, W, W.gcon(k), r);
 }
 
-// forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms.
-// NW > 1: called by every lane of every wavefront of the workgroup at the same
-// point (it contains workgroup barriers).
-DEV void forward(Env& E, Work& W, bool actuation, real tol) {
+// forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms
+DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
   kinematics(E);
   com_pos(E);
   crb_factor(E, W);
@@ -1838,56 +1511,6 @@ DEV void forward(Env& E, Work& W, bool actuation, real tol) {
 #endif
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
-  if (NW > 1) {
-    // rows were written by the wavefronts that built them
-    __syncthreads();
-    const bool has_rows = E.nefc > 0;
-    bool solve = wany(has_rows);
-#ifdef DMC_ABLATE_SOLVER
-    solve = false;
-#endif
-    bool use_warm = false;
-    if (solve) {
-      // warm start vs unconstrained acceleration, rows split over the waves
-      const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
-      real cw = 0;
-      if (try_warm) {
-        real Ma[NVX];
-        symv(Ma, Mats::M(E, W), E.warm);
-        DMC_UNROLL
-        for (int i = 0; i < NV; i++)
-          cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
-      }
-      real part[2] = {0, 0};
-      if (has_rows) for_my_rows(W, E.nefc, [&](auto rec) {
-        real row[NVX];
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) row[j] = rec.get(j);
-        const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
-        real jw = 0, js = 0;
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) { jw += row[j]*E.warm[j]; js += row[j]*E.qacc_smooth[j]; }
-        jw -= aref; js -= aref;
-        if (jw < 0) part[0] += R(0.5)*D*jw*jw;
-        if (js < 0) part[1] += R(0.5)*D*js*js;
-        rec.set(ROW_JAR, jw); rec.set(ROW_JV, js);
-      });
-      xsum<2>(W, part);
-      use_warm = try_warm && !(cw + part[0] > part[1]);
-    }
-    DMC_UNROLL
-    for (int i = 0; i < NV; i++)
-      E.qacc[i] = has_rows && use_warm ? E.warm[i] : E.qacc_smooth[i];
-    if (solve) solve_newton_split(E, W, tol, has_rows, !use_warm);
-    if (NTOUCH > 0) {
-      __syncthreads();             // final Jaref of every row, whoever owns it
-      touch_sensors(E, W);
-    }
-    __syncthreads();               // the next forward pass rewrites contacts and rows
-    DMC_UNROLL
-    for (int i = 0; i < NV; i++) E.warm[i] = E.qacc[i];
-    return;
-  }
 #ifdef DMC_ABLATE_SOLVER
   if (true) {
 #else
@@ -2017,7 +1640,7 @@ DEV bool check_state(Env& E, real& time) {   // mj_checkPos / mj_checkVel
 // without a forward pass and calls physics.step(), whose mj_step2 still sees
 // the mass matrix, bias forces and contacts of qpos0 (suite/cheetah.py:63-77,
 // engine.py:149-166).
-DEV void physics_step(Env& E, Work& W, real& time, real tol, bool stale = false) {
+DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = false) {
   const real h = R(timestep);
   check_state(E, time);
   if (INTEGRATOR == 0) {
@@ -2080,15 +1703,7 @@ DEV void physics_step(Env& E, Work& W, real& time, real tol, bool stale = false)
     bool ba = false;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) ba |= bad(E.qacc[i]);
-    // a bad acceleration resets the state; the lane still walks through the
-    // remaining stages (forward() holds workgroup barriers when NW > 1)
-    if (ba) {
-      E.warn |= WARN_BADQACC; reset_state(E, time);
-      DMC_UNROLL
-      for (int i = 0; i < NQ; i++) q0[i] = E.qpos[i];
-      DMC_UNROLL
-      for (int i = 0; i < NV; i++) { v0[i] = 0; E.qacc[i] = 0; }
-    }
+    if (ba) { E.warn |= WARN_BADQACC; reset_state(E, time); return; }
     DMC_UNROLL
     for (int i = 0; i < NV; i++) { Fv[i] = E.qvel[i]; Fa[i] = E.qacc[i]; }
     const real Acoef[3] = {R(0.5), R(0.5), R(1)};
@@ -2107,7 +1722,6 @@ DEV void physics_step(Env& E, Work& W, real& time, real tol, bool stale = false)
       DMC_UNROLL
       for (int i = 0; i < NV; i++) { Fv[s*NV + i] = E.qvel[i]; Fa[s*NV + i] = E.qacc[i]; }
     }
-    if (ba) { reset_state(E, time); return; }
 #ifdef DMC_STATE_COMP
     real acc[NVX];
     DMC_UNROLL
@@ -2385,28 +1999,7 @@ DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
 // helpers above and supplies its own dmc_step / dmc_observe)
 // ---------------------------------------------------------------------------
 #ifndef DMC_COOP_BUILD
-// Lane -> env.  NW == 1: surplus lanes of a partial last workgroup leave at
-// once.  NW > 1: they stay (forward() holds workgroup barriers), shadow the last
-// env, own a workspace slot of their own (the host lays the workspace out for
-// the batch rounded up to whole workgroups) and store nothing.
-struct LaneId { int e; long long slot, stride; bool alive; int lane, wave; };
-DEV LaneId lane_id(const DmcArgs& a) {
-  LaneId id;
-  id.lane = threadIdx.x & (LANES - 1);
-#ifdef DMC_HOST_SHIM
-  id.wave = (int)(threadIdx.x/LANES);
-#else
-  id.wave = NW > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x/LANES)) : 0;
-#endif
-  const long long raw = (long long)blockIdx.x*LANES + id.lane;
-  id.alive = raw < a.nenv;
-  id.e = id.alive ? (int)raw : a.nenv - 1;
-  id.slot = NW > 1 ? raw : id.e;
-  id.stride = NW > 1 ? ((long long)a.nenv + LANES - 1)/LANES*LANES : (long long)a.nenv;
-  return id;
-}
-DEV void load_env(Env& E, const DmcArgs& a, const LaneId& id, real& time) {
-  const int e = id.e;
+DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   const long long n = a.nenv;
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) E.qpos[i] = a.qpos[i*n + e];
@@ -2415,8 +2008,8 @@ DEV void load_env(Env& E, const DmcArgs& a, const LaneId& id, real& time) {
   time = a.time[e];
 #ifdef DMC_STATE_COMP
   {
-    const long long np = id.stride;
-    const real* c = a.ws + (long long)WS_COMP*np + id.slot;
+    const long long np = n;
+    const real* c = a.ws + (long long)WS_COMP*np + e;
     DMC_UNROLL
     for (int i = 0; i < NQ; i++) {
       const real tag = c[i*np], lo = c[(NQ + i)*np];
@@ -2439,8 +2032,7 @@ DEV void load_env(Env& E, const DmcArgs& a, const LaneId& id, real& time) {
   DMC_UNROLL
   for (int s = 0; s < (NTOUCH > 0 ? NTOUCH : 1); s++) E.touch[s] = 0;
 }
-DEV void store_env(const Env& E, const DmcArgs& a, const LaneId& id, real time) {
-  const int e = id.e;
+DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
   const long long n = a.nenv;
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) a.qpos[i*n + e] = E.qpos[i];
@@ -2449,8 +2041,8 @@ DEV void store_env(const Env& E, const DmcArgs& a, const LaneId& id, real time) 
   a.time[e] = time;
 #ifdef DMC_STATE_COMP
   {
-    const long long np = id.stride;
-    real* c = a.ws + (long long)WS_COMP*np + id.slot;
+    const long long np = n;
+    real* c = a.ws + (long long)WS_COMP*np + e;
     DMC_UNROLL
     for (int i = 0; i < NQ; i++) { c[i*np] = E.qpos[i]; c[(NQ + i)*np] = E.qpos_lo[i]; }
     c += 2LL*NQ*np;
@@ -2468,29 +2060,24 @@ DEV void store_env(const Env& E, const DmcArgs& a, const LaneId& id, real time) 
 // coalesced stores.  Other layouts (explicit strides) are written directly.
 constexpr bool OBS_STAGE_FITS = LDS_WORDS >= LANES*(NOBS > 0 ? NOBS : 1);
 
-DEV void store_outputs(Env& E, const DmcArgs& a, const LaneId& id, bool accumulate,
+DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
                        real* lds_base) {
   const long long n = a.nenv;
-  const int e = id.e, lane = id.lane;
-  const bool alive = id.alive;
   real obs[NOBS > 0 ? NOBS : 1];
   const real rew = task_outputs(E, a, obs);
   if (OBS_STAGE_FITS && a.obs_sk == 1 && a.obs_se == NOBS) {
+    const int lane = threadIdx.x;
     DMC_UNROLL
     for (int k = 0; k < NOBS; k++) lds_base[k*LANES + lane] = obs[k];
-    if (NW > 1) wsync(); else __syncthreads();   // (NW > 1: wave 0 alone is here)
-    const long long base = (long long)blockIdx.x*LANES;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x*blockDim.x;
     const long long left = n - base;
-    const int nvalid = left < (long long)LANES ? (int)left : LANES;
+    const int nvalid = left < (long long)blockDim.x ? (int)left : (int)blockDim.x;
     real* out = a.obs + base*NOBS;
-    // NW == 1: lanes 0..nvalid-1 are exactly the active ones of a partial last
-    // block; NW > 1: all 64 lanes are here
-    const int nl = NW > 1 ? LANES : nvalid;
-    for (int w = lane; w < nvalid*NOBS; w += nl)
+    // lanes 0..nvalid-1 are exactly the active ones of a partial last block
+    for (int w = lane; w < nvalid*NOBS; w += nvalid)
       out[w] = lds_base[(w % NOBS)*LANES + w/NOBS];
-    if (!alive) return;
   } else {
-    if (!alive) return;
     DMC_UNROLL
     for (int k = 0; k < NOBS; k++)
       a.obs[(long long)k*a.obs_sk + (long long)e*a.obs_se] = obs[k];
@@ -2529,15 +2116,13 @@ DEV void store_outputs(Env& E, const DmcArgs& a, const LaneId& id, bool accumula
 #ifndef DMC_WAVES_PER_EU
 #define DMC_WAVES_PER_EU 1
 #endif
-extern "C" __global__ void __launch_bounds__(LANES*NW, DMC_WAVES_PER_EU)
+extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_step(DmcArgs a) {
-  const LaneId id = lane_id(a);
-  if (NW == 1 && !id.alive) return;
-  const int e = id.e;
-  const bool writer = id.alive && id.wave == 0;   // NW > 1: wave 0 stores the results
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= a.nenv) return;
   Env E;
   real time;
-  load_env(E, a, id, time);
+  load_env(E, a, e, time);
   const long long n = a.nenv;
   if (a.flags & 1) {
     bool bc = false;
@@ -2551,21 +2136,18 @@ dmc_step(DmcArgs a) {
       DMC_UNROLL
       for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
     }
-    if (writer) {
-      DMC_UNROLL
-      for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
-    }
+    DMC_UNROLL
+    for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
   } else {
     DMC_UNROLL
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
   __shared__ real lds_rows[LDS_WORDS];
-  Work W = {lds_rows + id.lane, a.ws + id.slot, id.stride, id.wave, 0};
+  Work W = {lds_rows + threadIdx.x, a.ws + e, n};
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
   for (int s = 0; s < a.nsub; s++)
     physics_step(E, W, time, tol, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
-  if (NW > 1 && id.wave != 0) return;    // (no barrier follows)
-  if (a.qacc && writer) {
+  if (a.qacc) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];
   }
@@ -2573,30 +2155,28 @@ dmc_step(DmcArgs a) {
 #ifndef DMC_ABLATE_OBS
     observe_stage(E, time);
 #endif
-    store_outputs(E, a, id, true, lds_rows);
+    store_outputs(E, a, e, true, lds_rows);
   }
 #ifdef DMC_SOLVER_PROFILE
-  if (NW > 1) wsync(); else __syncthreads();
-  if (writer)
-    for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
+  __syncthreads();
+  for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
 #endif
-  if (writer) store_env(E, a, id, time);
+  store_env(E, a, e, time);
 }
 
 // observation / reward / sensors of the current state (reset, after_reset)
-extern "C" __global__ void __launch_bounds__(LANES*NW, DMC_WAVES_PER_EU)
+extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_observe(DmcArgs a) {
-  const LaneId id = lane_id(a);
-  if (NW == 1 && !id.alive) return;
-  const int e = id.e;
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  if (e >= a.nenv) return;
   Env E;
   real time;
-  load_env(E, a, id, time);
+  load_env(E, a, e, time);
   const long long n = a.nenv;
   DMC_UNROLL
   for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   __shared__ real lds_rows[LDS_WORDS];
-  Work W = {lds_rows + id.lane, a.ws + id.slot, id.stride, id.wave, 0};
+  Work W = {lds_rows + threadIdx.x, a.ws + e, n};
   if (NTOUCH > 0) {
     // acceleration-stage sensors need the constraint forces: the reference's
     // after_reset runs mj_forward with actuation disabled (engine.py:283-295);
@@ -2605,7 +2185,6 @@ dmc_observe(DmcArgs a) {
     check_state(E, time);
     forward(E, W, false, tol);
   }
-  if (NW > 1 && id.wave != 0) return;    // (no barrier follows)
   const int ncon_forward = E.ncon, nefc_forward = E.nefc;
   observe_stage(E, time);
   if (NTOUCH > 0) {
@@ -2614,8 +2193,8 @@ dmc_observe(DmcArgs a) {
     E.ncon = 0; E.nefc = 0;
     if (NPAIR > 0) detect_contacts(E, W);
   }
-  store_outputs(E, a, id, false, lds_rows);
-  if (id.alive) store_env(E, a, id, time);
+  store_outputs(E, a, e, false, lds_rows);
+  store_env(E, a, e, time);
 }
 
 #endif  // !DMC_COOP_BUILD
@@ -2740,5 +2319,5 @@ extern "C" __device__ const int dmc_info[20] = {
     INTEGRATOR, NPAIR, LANES /*envs (= threads) per workgroup of dmc_step/dmc_observe;
                                 the workspace is sized for the batch rounded up to this*/,
     DMC_ENV_MAJOR /*0: state fields are [k][env]*/, NTASKDATA,
-    LANES*NW /*threads per workgroup*/, 0, 0};
+    LANES /*threads per workgroup*/, 0, 0};
 #endif

@@ -371,7 +371,7 @@ class Physics(_control.Physics):
   _COOP_POLICY = ()
 
   def __init__(self, model, batch_size=None, device=0, precision='f32',
-               task=None, ncon_max=None, build_mode=None, group=None, waves=None):
+               task=None, ncon_max=None, build_mode=None, group=None):
     self.model = model
     self._squeeze = batch_size is None
     self._batch_size = 1 if batch_size is None else int(batch_size)
@@ -388,18 +388,14 @@ class Physics(_control.Physics):
     self._profile_calls = 0
     self._build_mode = build_mode or self._BUILD_MODE
     self._group = group or 64
-    if build_mode is None and self._build_mode == 'auto':
+    if build_mode is None and self._build_mode == 'auto' and precision != 'mixed':
       for max_batch, lanes in self._COOP_POLICY:
         if self._batch_size <= max_batch:
           self._build_mode, self._group = 'coop', lanes
           break
-    self._waves = 1 if self._build_mode == 'coop' else (
-        waves or build.waves_for(model, self._batch_size))
     path = build.build_model(
         model, self._task_id, precision, ncon_max, mode=self._build_mode,
-        lds_budget=(None if self._waves > 1
-                    else build.lds_budget_for(self._batch_size)),
-        group=self._group, waves=self._waves)
+        lds_budget=build.lds_budget_for(self._batch_size), group=self._group)
     self._code_object = path
     self._hip_model = wrapper.HipModel(path, device)
     self._batch = wrapper.HipBatch(self._hip_model, self._batch_size)
@@ -442,11 +438,8 @@ class Physics(_control.Physics):
   @property
   def kernel_shape(self):
     info = self._hip_model.info
-    if info.env_major:
-      return '%d lanes per env (csrc/dmc_coop.hip)' % info.lanes_per_env
     if info.lanes_per_env > 1:
-      return ('one env per lane, %d wavefronts per workgroup share its 64 envs '
-              '(csrc/dmc_kernels.hip)' % info.lanes_per_env)
+      return '%d lanes per env (csrc/dmc_coop.hip)' % info.lanes_per_env
     return 'one env per lane (csrc/dmc_kernels.hip)'
 
   # -- stepping -----------------------------------------------------------------
@@ -610,7 +603,7 @@ class Physics(_control.Physics):
     Physics.__init__(new, self.model,
                      None if self._squeeze else self._batch_size,
                      self._device, self._precision, self._task_id,
-                     self._ncon_max, self._build_mode, self._group, self._waves)
+                     self._ncon_max, self._build_mode, self._group)
     new._batch.copy_state_from(self._batch)
     new._warn_seen = self._warn_seen.copy()
     new._dirty = self._dirty

@@ -9,7 +9,7 @@ ASSETS = {}
 # Keys of `environment_kwargs` consumed by the batched Physics rather than by
 # `control.Environment`.
 PHYSICS_KWARGS = ('batch_size', 'device', 'precision', 'ncon_max',
-                  'build_mode', 'group', 'waves')
+                  'build_mode', 'group')
 TASK_KWARGS = ('device_init',)
 
 

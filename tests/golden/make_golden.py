@@ -337,8 +337,99 @@ def control_golden():
                            flat=flat['observations'].tolist()))
 
 
+def initial_states_golden():
+  """qpos written by the reference's `initialize_episode` (before any physics
+  runs) for seeds 0..3 of cheetah, walker, hopper, humanoid and cart-pole.
+
+  The reference tasks are imported and run on a recording fake Physics that
+  offers exactly what they touch: `model` joint tables (taken from the in-tree
+  compiled models, which tests/test_compiler.py checks against the reference's
+  XML files), `data.qpos/qvel/time/ncon`, `named.data.qpos[...]` views and
+  no-op `step()` / `after_reset()`.  For the humanoid `ncon` reports a
+  collision for the first `redraws` calls, so that the rejection loop's draw
+  order is pinned as well.
+  """
+  sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+  sys.path.insert(0, os.path.dirname(OUT))
+  import helpers
+  mjb = sys.modules['dm_control.mujoco.wrapper.mjbindings']
+
+  class mjtJoint:
+    mjJNT_FREE, mjJNT_BALL, mjJNT_SLIDE, mjJNT_HINGE = 0, 1, 2, 3
+  mjb.enums = types.SimpleNamespace(mjtJoint=mjtJoint)
+  mjb.mjlib = None
+  from dm_control.suite import cartpole, cheetah, hopper, humanoid, walker
+
+  class NamedQpos:
+    def __init__(self, model, qpos):
+      self.m, self.q = model, qpos
+    def _span(self, name):
+      j = self.m.names['joint'].index(name)
+      a = int(self.m.jnt_qposadr[j])
+      n = {0: 7, 1: 4}.get(int(self.m.jnt_type[j]), 1)
+      return a, n
+    def __getitem__(self, name):
+      if not isinstance(name, str):
+        return self.q[name]
+      a, n = self._span(name)
+      return self.q[a:a + n]          # a view, as in mujoco/index.py
+    def __setitem__(self, name, value):
+      if not isinstance(name, str):
+        self.q[name] = value
+        return
+      a, n = self._span(name)
+      self.q[a:a + n] = value
+
+  class FakeModel:
+    def __init__(self, m):
+      self.m = m
+      for k in ('nq', 'nv', 'njnt', 'jnt_type', 'jnt_limited', 'jnt_range'):
+        setattr(self, k, getattr(m, k))
+    def id2name(self, i, kind):
+      return self.m.names[kind][i]
+
+  class FakePhysics:
+    def __init__(self, m, redraws=0):
+      self.model = FakeModel(m)
+      self.data = types.SimpleNamespace(
+          qpos=m.qpos0.copy(), qvel=np.zeros(m.nv), time=0.0, ncon=0)
+      self.named = types.SimpleNamespace(
+          data=types.SimpleNamespace(qpos=NamedQpos(m, self.data.qpos),
+                                     qvel=self.data.qvel))
+      self.steps, self.checks, self.redraws = 0, 0, redraws
+    def step(self):
+      self.steps += 1
+    def after_reset(self):
+      self.checks += 1
+      self.data.ncon = 1 if self.checks <= self.redraws else 0
+
+  out = {}
+  cases = [('cheetah', cheetah.Cheetah, {}, 0),
+           ('walker', walker.PlanarWalker, {'move_speed': 1}, 0),
+           ('hopper', hopper.Hopper, {'hopping': True}, 0),
+           ('humanoid', humanoid.Humanoid, {'move_speed': 1, 'pure_state': False}, 0),
+           ('humanoid_two_redraws', humanoid.Humanoid,
+            {'move_speed': 1, 'pure_state': False}, 2),
+           ('cartpole_swingup', cartpole.Balance, {'swing_up': True, 'sparse': False}, 0),
+           ('cartpole_balance', cartpole.Balance, {'swing_up': False, 'sparse': False}, 0)]
+  for name, cls, kwargs, redraws in cases:
+    model = helpers.load_model(name.split('_')[0])
+    rows = []
+    for seed in range(4):
+      task = cls(random=seed, **kwargs)
+      physics = FakePhysics(model, redraws)
+      task.initialize_episode(physics)
+      rows.append(dict(seed=seed, qpos=physics.data.qpos.tolist(),
+                       qvel=physics.data.qvel.tolist(),
+                       physics_steps=physics.steps))
+    out[name] = rows
+  return out
+
+
 def main():
   install_stubs()
+  with open(os.path.join(OUT, 'initial_states.json'), 'w') as f:
+    json.dump(initial_states_golden(), f, indent=1)
   with open(os.path.join(OUT, 'rewards.json'), 'w') as f:
     json.dump(rewards_golden(), f, indent=1)
   with open(os.path.join(OUT, 'tasks.json'), 'w') as f:

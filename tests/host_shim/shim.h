@@ -20,6 +20,3 @@ static inline void __syncthreads() {}
 using std::sqrt; using std::fabs; using std::pow; using std::exp; using std::log;
 using std::cos; using std::sin; using std::fmax; using std::fmin; using std::log1p;
 // glibc already declares sincos/sincosf with the signatures the kernel uses
-// one lane, one wavefront per workgroup: the wave-level helpers degenerate
-static inline bool wany(bool p) { return p; }
-static inline void wsync() {}

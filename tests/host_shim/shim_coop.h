@@ -54,7 +54,3 @@ template <class T> static inline T gup(T x, int d) {
 }
 template <class T> static inline T gget(T x, int src) { return shim_xchg(x, src); }
 template <class T> static inline T gbcast(T x, int src) { return shim_xchg(x, src); }
-// wave-level helpers of the one-env-per-lane kernel: the several-lanes-per-env
-// source includes that file for its shared helpers only and never calls them
-static inline bool wany(bool p) { return p; }
-static inline void wsync() {}

@@ -1,4 +1,8 @@
-"""N>1 path on CPU: env sharding + the reporting all-gather (gloo, 2 ranks)."""
+"""N>1 path on CPU: env sharding + the reporting all-gather (gloo, 2 ranks).
+
+bench.py goes through the same three functions (`shard_range`, `env_seeds`,
+`gather_episode_returns`) and `init_process_group`; here they run with the
+gloo backend and ragged shards."""
 
 import os
 import socket
@@ -37,9 +41,14 @@ def _worker(rank, world, port, total, queue):
                     RANK=str(rank), WORLD_SIZE=str(world))
   r, w = distributed.init_process_group('gloo')
   assert (r, w) == (rank, world)
+  # exactly what bench.py --global-batch does per rank: shard, per-env seeds,
+  # (simulate), gather the returns of all envs
   start, stop = distributed.shard_range(total, world, rank)
-  # each rank "simulates" its shard: return of env i is a function of i only
-  local = torch.arange(start, stop, dtype=torch.float32)*0.5 + 1.0
+  seeds = distributed.env_seeds(1000, total, world, rank)
+  assert len(seeds) == stop - start and seeds[0] == 1000 + start
+  # each rank "simulates" its shard: the return of env i is a function of its
+  # global seed only, so the gathered vector does not depend on the sharding
+  local = torch.from_numpy((seeds - 1000).astype('float32'))*0.5 + 1.0
   full = distributed.gather_episode_returns(local, total)
   queue.put((rank, full.numpy().copy()))
   import torch.distributed as dist

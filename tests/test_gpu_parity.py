@@ -7,8 +7,9 @@ against that oracle ("parity unpinned" beyond the KATs).
 
 Tolerances (relative error = max|a-b| / max(1, max|b|) over a state vector):
   fp64 build  teacher-forced 1 step   <= 1e-9      free-run 100 steps <= 1e-6
-  fp32 build  teacher-forced 1 step   <= 2e-4 (median <= 2e-6)
-              free-run, cartpole 1000 steps: median <= 1e-4, p90 <= 2e-3
+  fp32 build  teacher-forced 1 step: per model, ~10x what was observed on
+              MI355X in round 2 (FP32_PER_STEP below; medians 9e-9 ... 1e-6)
+              free-run 1000 steps: see test_north_star_1000_step_free_run
 Contact-rich chaotic systems (cheetah, humanoid) are compared teacher-forced
 in fp32; free-running fp32 vs fp64 trajectories separate exponentially after
 the first contact-set change, as for any two fp32/fp64 runs of MuJoCo itself.
@@ -35,12 +36,30 @@ pytestmark = pytest.mark.gpu
 
 W = wrapper
 
+# fp32 teacher-forced per-step error (median, p99, max) asserted per model:
+# about 10x the values observed on MI355X (round 2, both kernels; observed
+# medians: cartpole 3.6e-8, cheetah 1.2e-7, humanoid 9.6e-7, walker 6.6e-7,
+# pendulum 3.5e-8, acrobot 4.3e-8, hopper 2.9e-7, reacher 1.1e-7, point_mass
+# 8.7e-9; observed maxima 1.1e-7 ... 1.2e-4)
+FP32_PER_STEP = {
+    'cartpole': (4e-7, 1e-6, 2e-6), 'cheetah': (1.5e-6, 3e-5, 2e-4),
+    'humanoid': (1e-5, 1.5e-4, 1.5e-3), 'walker': (8e-6, 8e-5, 5e-4),
+    'pendulum': (4e-7, 1.2e-6, 2e-6), 'acrobot': (5e-7, 1.2e-6, 3e-6),
+    'hopper': (3e-6, 5e-5, 3e-4), 'reacher': (1.2e-6, 1.2e-5, 3e-5),
+    'point_mass': (1e-7, 2.5e-6, 2e-5)}
+
+
+def _assert_fp32_per_step(name, e):
+  med, p99, top = FP32_PER_STEP[name]
+  assert np.median(e) <= med, (name, np.median(e))
+  assert np.percentile(e, 99) <= p99, (name, np.percentile(e, 99))
+  assert e.max() <= top, (name, e.max())
+
 
 def _device_batch(model, task, precision, nenv, mode='auto', lds_budget=None,
-                  group=64, waves=1):
+                  group=64):
   hm = W.HipModel(build.build_model(model, task, precision, mode=mode,
-                                    lds_budget=lds_budget, group=group,
-                                    waves=waves))
+                                    lds_budget=lds_budget, group=group))
   return hm, W.HipBatch(hm, nenv)
 
 
@@ -66,10 +85,10 @@ def _degenerate(d, model):
 
 
 def _teacher_forced(name, precision, nenv, steps, nsub, lds_budget=None,
-                    mode=None, group=64, waves=1):
+                    mode=None, group=64):
   model = helpers.load_model(name)
   hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv,
-                         mode or helpers.MODES[name], lds_budget, group, waves)
+                         mode or helpers.MODES[name], lds_budget, group)
   qpos, qvel = helpers.initial_states(model, name, nenv, seed=7)
   om, datas = _oracle_envs(model, qpos, qvel)
   rs = np.random.RandomState(11)
@@ -116,9 +135,7 @@ def test_fp32_build_matches_oracle_per_step(name, nsub):
   e = _teacher_forced(name, 'f32', nenv=128, steps=12, nsub=nsub)
   print('OBSERVED fp32 per-step %s: median %.2e p99 %.2e max %.2e'
         % (name, np.median(e), np.percentile(e, 99), e.max()))
-  assert np.median(e) <= 2e-6, np.median(e)
-  assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
-  assert e.max() <= 5e-3, e.max()
+  _assert_fp32_per_step(name, e)
 
 
 @pytest.mark.parametrize('name,nsub,group', [
@@ -137,42 +154,7 @@ def test_several_lanes_per_env_build_matches_oracle(name, nsub, group):
                       group=group)
   print('OBSERVED fp32 per-step coop %s G=%d: median %.2e p99 %.2e max %.2e'
         % (name, group, np.median(e), np.percentile(e, 99), e.max()))
-  assert np.median(e) <= 2e-6, np.median(e)
-  assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
-
-
-@pytest.mark.parametrize('name,nsub', [('cheetah', 1), ('walker', 10), ('hopper', 4)])
-def test_four_wavefronts_per_workgroup_match_oracle(name, nsub):
-  """-DDMC_WAVES=4 (what `Physics` picks for the models with contacts up to
-  16384 envs): four wavefronts share a workgroup's 64 envs and split the passes
-  over the constraint rows; partial sums meet behind workgroup barriers.  Odd
-  batch sizes: partially filled last workgroups, whose surplus lanes stay in
-  the kernel for the barriers."""
-  e = _teacher_forced(name, 'f64', nenv=97, steps=10, nsub=nsub, waves=4)
-  assert e.max() <= 1e-9, e.max()
-  e = _teacher_forced(name, 'f32', nenv=130, steps=10, nsub=nsub, waves=4)
-  print('OBSERVED fp32 per-step waves=4 %s: median %.2e p99 %.2e max %.2e'
-        % (name, np.median(e), np.percentile(e, 99), e.max()))
-  assert np.median(e) <= 2e-6, np.median(e)
-  assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
-  # and the same trajectories as the one-wavefront build up to rounding
-  model = helpers.load_model(name)
-  qpos, qvel = helpers.initial_states(model, name, 200, seed=3)
-  ctrl = np.random.RandomState(5).uniform(-1, 1, (8, 200, model.nu))
-  out = []
-  for waves in (1, 4):
-    hm, hb = _device_batch(model, helpers.TASKS[name], 'f64', 200, waves=waves)
-    assert hm.info.lanes_per_env == waves and not hm.info.env_major
-    hb.set_state(qpos.T, qvel.T)
-    for t in range(8):
-      hb.step_host(ctrl[t], nsub)
-    out.append((hb.read(W.FIELD_QPOS), hb.read(W.FIELD_QVEL), hb.read(W.FIELD_OBS),
-                hb.read(W.FIELD_STATS)[:2]))
-    hb.free()
-  np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=1e-9)
-  np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-7)
-  np.testing.assert_allclose(out[0][2], out[1][2], rtol=0, atol=1e-7)
-  np.testing.assert_array_equal(out[0][3], out[1][3])      # same contacts and rows
+  _assert_fp32_per_step(name, e)
 
 
 @pytest.mark.parametrize('mode', ['unrolled', 'coop'])
@@ -209,33 +191,38 @@ def test_touch_sensors_match_oracle(mode):
   hb.free()
 
 
-def test_first_timestep_touch_of_a_hopper_in_contact():
-  """The FIRST TimeStep's `touch` observation: the reference's after_reset runs
-  mj_forward with actuation disabled (engine.py:283-295), so the touch sensors
-  of the randomised start pose -- random ankle angles put the toe through the
-  floor -- hold the contact forces of that pose, not zero."""
+def test_touch_after_reset_of_a_hopper_in_contact():
+  """`after_reset` (what produces the FIRST TimeStep's observation): the
+  reference runs mj_forward with actuation disabled there (engine.py:283-295),
+  so the touch sensors hold the contact forces of the start pose.  Poses with
+  the foot in the floor, through `Physics.after_reset` -- the launch that also
+  counts contacts -- against the oracle's forward pass."""
   nenv = 64
   env = suite.load('hopper', 'stand', task_kwargs={'random': 3},
                    environment_kwargs={'batch_size': nenv, 'precision': 'f64'})
   ts = env.reset()
-  physics = env.physics
+  assert ts.first() and ts.observation['touch'].shape == (nenv, 2)
+  physics, task = env.physics, env.task
   model = physics.model
-  qpos = np.asarray(physics.data.qpos)
-  qvel = np.asarray(physics.data.qvel)
+  qpos, qvel = helpers.initial_states(model, 'hopper', nenv, seed=2)
+  physics.set_state(np.hstack([qpos, qvel]))
+  physics.after_reset()
+  touch = task.get_observation(physics)['touch']
   want = np.zeros((nenv, 2))
+  ncon = np.zeros(nenv, int)
   for i in range(nenv):
     p = oracle.OraclePhysics(model)
     p.reset()
     p.data.qpos[:] = qpos[i]
     p.data.qvel[:] = qvel[i]
+    p.data.ctrl[:] = 1
     p.after_reset()
+    ncon[i] = p.data.ncon
     want[i] = [helpers.oracle_touch(model, p.data, n)
                for n in ('touch_toe', 'touch_heel')]
-  assert (want > 0).sum() > nenv//4            # many start poses touch the floor
-  np.testing.assert_allclose(ts.observation['touch'], np.log1p(want),
-                             rtol=1e-6, atol=1e-9)
-  assert np.array_equal(physics.data.ncon > 0, (want.sum(axis=1) > 0) |
-                        (np.asarray(physics.data.ncon) > 0))
+  assert (want > 0).sum() > nenv//4            # many of these poses press on the floor
+  np.testing.assert_allclose(touch, np.log1p(want), rtol=1e-6, atol=1e-9)
+  np.testing.assert_array_equal(np.asarray(physics.data.ncon), ncon)
   physics.free()
 
 
@@ -248,8 +235,7 @@ def test_high_occupancy_variants_match_oracle(lds_budget):
   multiply-adds differently between the variants, so not bit-identical)."""
   e = _teacher_forced('cheetah', 'f32', nenv=128, steps=12, nsub=1,
                       lds_budget=lds_budget)
-  assert np.median(e) <= 2e-6, np.median(e)
-  assert np.percentile(e, 99) <= 2e-4, np.percentile(e, 99)
+  _assert_fp32_per_step('cheetah', e)
   model = helpers.load_model('cheetah')
   qpos, qvel = helpers.initial_states(model, 'cheetah', 256, seed=3)
   ctrl = np.random.RandomState(5).uniform(-1, 1, (12, 256, model.nu))
@@ -311,17 +297,27 @@ def test_fp32_cartpole_free_run_1000_steps():
   # random torques drive some poles slowly through the upright (unstable)
   # equilibrium, where any rounding difference is amplified: the bulk of the
   # batch stays at fp32 resolution, the tail is reported, not hidden.
+  # (observed on MI355X, round 2: median 1.0e-5, p90 1.5e-4, max 0.2)
   assert np.median(eq) <= 1e-4, np.median(eq)
-  assert np.percentile(eq, 90) <= 2e-3, np.percentile(eq, 90)
+  assert np.percentile(eq, 90) <= 1.5e-3, np.percentile(eq, 90)
+  assert np.mean(eq <= 1e-4) >= 0.75, np.mean(eq <= 1e-4)
   assert eq.max() <= 0.5, eq.max()
 
 
-@pytest.mark.parametrize('key', sorted(kat_models.GPU_MODELS))
-def test_known_answer_models_on_device(key):
-  """Box/sphere/capsule primitives and free joints through the HIP path."""
+@pytest.mark.parametrize('key,mode', [(k, 'auto') for k in sorted(kat_models.GPU_MODELS)] +
+                         [('primitives', 'unrolled'), ('primitives', 'rolled')])
+def test_known_answer_models_on_device(key, mode):
+  """Box/sphere/capsule primitives and free joints through the HIP path.
+
+  The 20-dof `primitives` model is also run in both explicit build modes: its
+  fp64 UNROLLED code object computed one dof's velocity wrongly by g*h on the
+  GPU in round 1 (hidden behind the spill-aware `auto` mode).  With the current
+  sources the unrolled build agrees with the oracle to 1e-15 per step
+  (tools/gpu_primitives_unrolled.py), the host build is clean under
+  MemorySanitizer, and this test keeps it that way."""
   model = compiler.from_xml_string(kat_models.GPU_MODELS[key])
   nenv = 32
-  hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv)
+  hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv, mode)
   rs = np.random.RandomState(2)
   qpos = np.tile(model.qpos0, (nenv, 1))
   qvel = 0.2*rs.randn(nenv, model.nv)
@@ -998,8 +994,12 @@ def test_north_star_1000_step_free_run(name):
       assert np.percentile(e, 90) <= 1e-4, np.percentile(e, 90)
       assert e.max() <= 5e-3, e.max()
     else:
+      # (observed: median 9.6e-7, p90 2.7e-6; an env whose contact sequence
+      # leaves the oracle's -- about 1 in 60, profiles/r02_precision_study_* --
+      # separates exponentially, hence a share and not a maximum)
       assert np.median(e) <= 1e-5, np.median(e)
-      assert np.mean(e <= 1e-4) >= 0.85, np.mean(e <= 1e-4)
+      assert np.percentile(e, 90) <= 3e-5, np.percentile(e, 90)
+      assert np.mean(e <= 1e-4) >= 0.9, np.mean(e <= 1e-4)
     hb.free()
 
 
@@ -1047,7 +1047,15 @@ def test_free_run_trajectories_several_lanes_kernel(name, nsub, steps):
     if precision == 'f64':
       assert e.max() <= 1e-5, e.max()
     else:
+      # falling, contact-rich bodies under random torques are chaotic: fp32
+      # rounding (per-step error ~1e-6) grows by orders of magnitude per hundred
+      # physics steps.  Observed medians after these horizons: humanoid 3.5e-3,
+      # hopper 4.2e-3, walker (1000 physics steps) 0.13 -- decorrelated; the
+      # bound is ~10x that where it still means something.
       assert np.isfinite(e).all()
+      limit = {'humanoid': 4e-2, 'hopper': 5e-2}.get(name)
+      if limit is not None:
+        assert np.median(e) <= limit, np.median(e)
     hb.free()
 
 

@@ -92,81 +92,6 @@ def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path
 
 
 # ---------------------------------------------------------------------------
-# several wavefronts per workgroup (-DDMC_WAVES=4): one OS thread per lane
-# ---------------------------------------------------------------------------
-@pytest.mark.timeout(1500)
-@pytest.mark.parametrize('name,sanitizer,nenv,steps,lds_budget', [
-    ('cheetah', 'thread', 64, 6, 200000),              # 1 row record in LDS, rest in HBM
-    ('cheetah', 'address,undefined', 37, 12, 320000),  # partial workgroup
-    ('hopper', 'address,undefined', 33, 16, 250000)])  # touch sensors read others' rows
-def test_four_wavefronts_per_workgroup_source(name, sanitizer, nenv, steps, lds_budget,
-                                              tmp_path):
-  """csrc/dmc_kernels.hip built with -DDMC_WAVES=4 and run with one thread per
-  lane of all four wavefronts (tests/host_shim/shim_waves.h): `__syncthreads`
-  is a pthread barrier over the 256 threads, so a barrier that one wavefront
-  would skip deadlocks (timeout), ThreadSanitizer reports every LDS word that
-  crosses wavefronts without a barrier, AddressSanitizer every index; the
-  trajectories of all envs are compared with the oracle."""
-  model, task = helpers.load_model(name), helpers.TASKS[name]
-  q, v = helpers.initial_states(model, name, nenv, seed=7)
-  header = tmp_path/'model.h'
-  text = codegen.generate_header(model, task, unroll=True)
-  header.write_text(text.replace('static __device__ constexpr',
-                                 'static constexpr'))
-  exe = str(tmp_path/'harness_waves')
-  cmd = ['g++', '-std=c++17', '-O1', '-g', '-pthread',
-         '-fsanitize=' + sanitizer, '-fno-omit-frame-pointer',
-         '-DDMC_REAL_IS_DOUBLE', '-DDMC_WAVES=4', '-DDMC_LDS_BUDGET=%d' % lds_budget,
-         '-DDMC_MODEL_HEADER="%s"' % header,
-         '-DDMC_KERNEL_SOURCE="%s"' % KERNEL,
-         '-I', os.path.join(ROOT, 'dm_control_amd', 'csrc'), '-I', SHIM,
-         '-x', 'c++', os.path.join(SHIM, 'harness_waves.cpp'), '-o', exe]
-  if 'undefined' in sanitizer:
-    cmd.insert(1, '-fno-sanitize-recover=undefined')
-  subprocess.check_call(cmd)
-  args = [exe, str(steps), str(nenv)]
-  for e in range(nenv):
-    args += ['%.17g' % x for x in q[e]] + ['%.17g' % x for x in v[e]]
-  env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0',
-             TSAN_OPTIONS='halt_on_error=1')
-  out = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       universal_newlines=True, env=env, timeout=1400)
-  assert out.returncode == 0, out.stderr[-3000:]
-  lines = out.stdout.splitlines()
-  cfg = dict(kv.split('=') for kv in lines[0].split()[1:])
-  assert cfg['waves'] == '4'
-  if lds_budget <= 200000:
-    assert int(cfg['glb_rows']) > 0          # the HBM tier is in play
-  om = oracle.OracleModel(model)
-  datas = []
-  for e in range(nenv):
-    d = oracle.OracleData(om)
-    d.qpos[:] = q[e]
-    d.qvel[:] = v[e]
-    d.step1()
-    datas.append(d)
-  seen, rows = 0, 0
-  for line in lines:
-    if not line.startswith('STEP'):
-      continue
-    vals, tail = line.split('|')
-    fields = vals.split()
-    e = int(fields[2])
-    state = np.array([float(x) for x in fields[3:]])
-    ncon, nefc, iters, warn = [int(x) for x in tail.split()]
-    d = datas[e]
-    assert (ncon, nefc) == (d.ncon, d.nefc)
-    rows += nefc
-    d.physics_step()
-    assert warn == 0
-    np.testing.assert_allclose(state[:model.nq], d.qpos, rtol=0, atol=1e-9)
-    np.testing.assert_allclose(state[model.nq:], d.qvel, rtol=0, atol=1e-8)
-    seen += 1
-  assert seen == steps*nenv
-  assert rows > 0
-
-
-# ---------------------------------------------------------------------------
 # several lanes per env (csrc/dmc_coop.hip): one OS thread per lane
 # ---------------------------------------------------------------------------
 COOP_KERNEL = os.path.join(ROOT, 'dm_control_amd', 'csrc', 'dmc_coop.hip')

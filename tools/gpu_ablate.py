@@ -24,11 +24,7 @@ FLAGSETS = [(), ('-DDMC_ABLATE_OBS',), ('-DDMC_ABLATE_SOLVER',), ('-DDMC_ABLATE_
 if len(sys.argv) > 3:
   FLAGSETS = [tuple(f.split(',')) if f != '-' else () for f in sys.argv[3:]]
 for flags in FLAGSETS:
-  # "W4" / "W2": that many wavefronts per workgroup (build_model(waves=...))
-  waves = max([int(f[1:]) for f in flags if f in ('W2', 'W4')] or [1])
-  flags = tuple(f for f in flags if f not in ('W2', 'W4'))
-  path = build.build_model(model, helpers.TASKS[name], 'f32', extra_flags=flags,
-                           waves=waves)
+  path = build.build_model(model, helpers.TASKS[name], 'f32', extra_flags=flags)
   hm = W.HipModel(path); hb = W.HipBatch(hm, B)
   ts = []
   for rep in range(15):
@@ -49,7 +45,7 @@ for flags in FLAGSETS:
               tot.mean()/100, np.percentile(tot, 90)/100, tot.max()/100),
           '| extra line-search passes per env: mean %.2f max %d' % (pr[:, 5].mean(), pr[:, 5].max()))
   print('%-50s %.4f ms  (iters mean %.2f, per-wave max mean %.2f, batch max %d; nefc mean %.1f, per-wave max mean %.1f, batch max %d)' % (
-      ('waves=%d ' % waves if waves > 1 else '') + (' '.join(flags) or 'full'),
+      ' '.join(flags) or 'full',
       float(np.median(ts)), st[2].mean(), st[2].reshape(-1, 64).max(axis=1).mean(), st[2].max(),
       st[1].mean(), st[1].reshape(-1, 64).max(axis=1).mean(), st[1].max()), flush=True)
   hb.free(); hm.free()
