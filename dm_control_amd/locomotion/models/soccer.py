@@ -1,0 +1,61 @@
+"""Frozen soccer scene: fixed-size pitch, ball, N position-controlled humanoids.
+
+Reference: locomotion/soccer/__init__.py:92-152 (loader), soccer/task.py:49,
+95-108 (physics timestep 0.005, `njmax`/`nconmax` per player),
+soccer/soccer_ball.py:29-96 (regulation ball: radius 0.35? no -- the defaults
+of `SoccerBall._build`: radius 0.35 m, mass 0.045 kg, friction (0.7, 0.075,
+0.075), condim 6, priority 1, solref (0.02, damp_ratio)), soccer/pitch.py
+(ground plane and four wall planes around it).
+
+Stage 1 scope (stated): the pitch is the ground plane plus the four wall planes
+at a fixed size -- `RandomizedPitch` resizes the arena and the composer
+recompiles the model every episode (composer/environment.py:321-333), which a
+frozen code object cannot follow; goal posts, nets and the field box (box
+geoms: the box narrowphase beyond plane-box is not built) are left out.
+"""
+
+from dm_control_amd.locomotion.models import cmu_humanoid
+from dm_control_amd.suite import models as m
+
+PHYSICS_TIMESTEP = 0.005           # soccer/task.py:105
+BALL = dict(radius=0.35, mass=0.045, friction=(0.7, 0.075, 0.075), damp_ratio=1.0)
+PITCH_SIZE = (9.0, 6.0)            # half extents of the fixed arena (m)
+
+
+def build(num_walkers=1, with_ball=True, pitch_size=PITCH_SIZE,
+          nconmax_per_player=200, njmax_per_player=200):
+  """MJCF string of the scene.  Walkers stand in a row facing the ball.
+
+  (Oracle and kernels address the dofs of a kinematic chain with 64-bit masks,
+  i.e. nv <= 64: one walker (62 dofs) OR ball + nothing else can be stepped
+  today; several walkers on one pitch are the next stage.)"""
+  root = m.node(None, 'mujoco', model='soccer_%d' % num_walkers)
+  m.node(root, 'option', timestep=PHYSICS_TIMESTEP)
+  m.node(root, 'size', nconmax=nconmax_per_player*max(1, num_walkers),
+         njmax=njmax_per_player*max(1, num_walkers))
+  cmu_humanoid.add_defaults(root)
+  world = m.node(root, 'worldbody')
+  actuator = m.node(root, 'actuator')
+  contact = m.node(root, 'contact')
+  # the reference pitch's plane geoms use MuJoCo's geom defaults, not the
+  # walker's: they are written out here because this document has ONE default set
+  plane = dict(type='plane', condim=3, friction=(1, 0.005, 0.0001),
+               solref=(0.02, 1), solimp=(0.9, 0.95, 0.001))
+  m.node(world, 'geom', name='ground', size=(pitch_size[0], pitch_size[1], 0.1), **plane)
+  lx, ly = pitch_size
+  walls = (('wall_ny', (0, -ly, 0), (-1, 0, 0, 0, 0, 1)), ('wall_py', (0, ly, 0), (1, 0, 0, 0, 0, 1)),
+           ('wall_nx', (-lx, 0, 0), (0, 1, 0, 0, 0, 1)), ('wall_px', (lx, 0, 0), (0, -1, 0, 0, 0, 1)))
+  for name, pos, xyaxes in walls:
+    m.node(world, 'geom', name=name, pos=pos, xyaxes=xyaxes, size=(max(lx, ly), 3.0, 0.1),
+           **plane)
+  if with_ball:
+    ball = m.node(world, 'body', name='ball', pos=(0, 0, BALL['radius'] + 0.01))
+    m.node(ball, 'freejoint', name='ball_free')
+    m.node(ball, 'geom', name='ball', type='sphere', size=(BALL['radius'],), condim=6,
+           priority=1, mass=BALL['mass'], friction=BALL['friction'],
+           solref=(0.02, BALL['damp_ratio']), solimp=(0.9, 0.95, 0.001))
+  for i in range(num_walkers):
+    side = -1 if i % 2 == 0 else 1
+    cmu_humanoid.add_walker(root, world, actuator, contact, prefix='walker%d/' % i,
+                            pos=(side*(1.5 + i//2), 0.6*(i//2), 1.05))
+  return m.to_string(root)

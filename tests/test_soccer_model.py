@@ -1,0 +1,232 @@
+"""Soccer, stage 1: the physics prerequisites only.
+
+The frozen scenes of dm_control_amd/locomotion/models -- position-controlled
+CMU humanoid on a fixed pitch, and the regulation ball -- against the reference
+data where the tree is present (parameter tables vs humanoid_CMU_V2019.xml),
+against closed forms (position actuators, weight on the floor, condim-6 /
+priority contact of the ball), and on the device against the oracle
+(`-m gpu`).  Composer, observables, mocap initialiser and per-episode
+recompilation are not built; several walkers on one pitch need chains beyond
+the 64-dof masks of oracle and kernels (next stage).
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from dm_control_amd import codegen
+from dm_control_amd.locomotion.models import cmu_humanoid_table as T
+from dm_control_amd.locomotion.models import soccer
+from dm_control_amd.mjcf import compiler
+from oracle import oracle
+
+REF_XML = ('/root/reference/dm_control/locomotion/walkers/assets/'
+           'humanoid_CMU_V2019.xml')
+
+
+def _walker_model():
+  return compiler.from_xml_string(soccer.build(1, with_ball=False))
+
+
+def _ball_model():
+  return compiler.from_xml_string(soccer.build(0, with_ball=True))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_XML), reason='reference tree absent')
+def test_tables_compile_like_the_reference_xml():
+  ref = compiler.from_xml_path(REF_XML)
+  m = _walker_model()
+  assert (m.nq, m.nv, m.nu) == (ref.nq + 7, ref.nv + 6, 56)
+  for name in [b[0] for b in T.BODIES]:
+    i, j = m.name2id('walker0/' + name, 'body'), ref.name2id(name, 'body')
+    np.testing.assert_allclose(m.body_pos[i], ref.body_pos[j], atol=1e-12)
+    np.testing.assert_allclose(m.body_quat[i], ref.body_quat[j], atol=1e-12)
+    if name not in ('lhand', 'rhand'):      # ellipsoid -> equal-volume sphere
+      np.testing.assert_allclose(m.body_inertia[i], ref.body_inertia[j], rtol=1e-10)
+    np.testing.assert_allclose(m.body_mass[i], ref.body_mass[j], rtol=1e-10)
+  for name in [j[0] for j in T.JOINTS]:
+    i, j = m.name2id('walker0/' + name, 'joint'), ref.name2id(name, 'joint')
+    np.testing.assert_allclose(m.jnt_axis[i], ref.jnt_axis[j], atol=1e-12)
+    np.testing.assert_allclose(m.jnt_range[i], ref.jnt_range[j], atol=1e-12)
+    np.testing.assert_allclose(m.jnt_stiffness[i], ref.jnt_stiffness[j])
+    di, dj = m.jnt_dofadr[i], ref.jnt_dofadr[j]
+    np.testing.assert_allclose(m.dof_damping[di], ref.dof_damping[dj])
+    np.testing.assert_allclose(m.dof_armature[di], ref.dof_armature[dj])
+  assert m.nexclude == ref.nexclude == len(T.EXCLUDES)
+
+
+def test_position_actuators_follow_the_scaled_actuator_formula():
+  """walkers/scaled_actuators.py: ctrl -1 / +1 ask for the ends of the joint
+  range; force = kp (target - q), clipped to the force range; MuJoCo's own
+  ctrl clamp applies before."""
+  m = _walker_model()
+  p = oracle.OraclePhysics(m)
+  p.reset()
+  rs = np.random.RandomState(0)
+  q = m.qpos0.copy()
+  hinge = {name: (rng, i) for i, (name, _, _, rng, _) in enumerate(T.JOINTS)}
+  for name, (rng, i) in hinge.items():
+    q[7 + i] = rs.uniform(*rng)
+  ctrl = rs.uniform(-1.3, 1.3, m.nu)
+  p.data.qpos[:] = q
+  p.data.ctrl[:] = ctrl
+  p.forward()
+  for a, (name, forcerange, kp) in enumerate(T.POSITION_ACTUATORS):
+    (lo, hi), i = hinge[name]
+    c = np.clip(ctrl[a], -1, 1)
+    target = lo + (hi - lo)*(c + 1)/2
+    want = np.clip(kp*(target - q[7 + i]), *forcerange)
+    dof = m.jnt_dofadr[m.name2id('walker0/' + name, 'joint')]
+    np.testing.assert_allclose(p.data.qfrc_actuator[dof], want, rtol=1e-9, atol=1e-9)
+  assert abs(p.data.qfrc_actuator[:6]).max() == 0        # nothing acts on the root
+
+
+def test_walker_comes_to_rest_on_its_weight():
+  m = _walker_model()
+  assert codegen.capacities(m, codegen.collision_pairs(m))[0] >= 16
+  p = oracle.OraclePhysics(m)
+  p.reset()
+  p.data.qpos[2] = 0.4                     # dropped from a crouch height
+  p.forward()
+  for _ in range(1500):
+    p.step()
+  assert not p.data.warning.any() and np.isfinite(p.data.qpos).all()
+  assert abs(p.data.qvel).max() < 0.05
+  p.data.step2()
+  normal = sum(p.data.contact_force(i)[0, 0] for i in range(p.data.ncon))
+  p.data.step1()
+  weight = 9.81*m.body_mass.sum()
+  assert p.data.ncon >= 3
+  assert abs(normal - weight) < 0.02*weight, (normal, weight)
+
+
+def test_ball_contact_is_condim_six_with_its_own_friction():
+  """soccer_ball.py:88-96: condim 6 and priority 1 -- the ball's parameters
+  win over the floor's: ten pyramid rows per contact, friction (0.7, 0.075,
+  0.075); a spinning, sliding ball is slowed down by all three of them."""
+  m = _ball_model()
+  pairs = codegen.collision_pairs(m)
+  ground = m.name2id('ground', 'geom')
+  ball = m.name2id('ball', 'geom')
+  mx = codegen.mix_pair(m, ground, ball)
+  assert mx['dim'] == 6
+  # contact friction = (slide, slide, spin, roll, roll) of the ball's (slide, spin, roll)
+  np.testing.assert_allclose(mx['friction'], [0.7, 0.7, 0.075, 0.075, 0.075])
+  assert (ground, ball) in pairs or (ball, ground) in pairs
+  p = oracle.OraclePhysics(m)
+  p.reset()
+  p.data.qpos[2] = soccer.BALL['radius']
+  p.data.qvel[:] = [2.0, 0, 0, 0, 0, 8.0]           # sliding along x, spinning about z
+  p.forward()
+  nefc_seen = 0
+  for _ in range(400):
+    p.step()
+    nefc_seen = max(nefc_seen, p.data.nefc)
+  assert nefc_seen == 10
+  assert not p.data.warning.any()
+  assert abs(p.data.qvel[5]) < 1.0          # torsional friction stopped the spin
+  assert 0 < p.data.qvel[0] < 2.0           # rolling now, slower than it slid
+  # rolling without slipping: v = omega x r  ->  v_x = omega_y * R
+  assert abs(p.data.qvel[0] - p.data.qvel[4]*soccer.BALL['radius']) < 0.05
+
+
+# ---------------------------------------------------------------------------
+# device (fp64 for the tight comparison, fp32 at full contact capacity)
+# ---------------------------------------------------------------------------
+def _states(m, nenv, rs, height):
+  qpos = np.tile(m.qpos0, (nenv, 1))
+  for i, (name, _, _, rng, _) in enumerate(T.JOINTS):
+    lo, hi = rng
+    qpos[:, 7 + i] = rs.uniform(lo + 0.1*(hi - lo), hi - 0.1*(hi - lo), nenv)
+  qpos[:, 7:] = 0.5*qpos[:, 7:] + 0.5*m.qpos0[7:]
+  quat = np.array([0.7071067811865476, 0.7071067811865476, 0, 0]) + 0.1*rs.randn(nenv, 4)
+  qpos[:, 3:7] = quat/np.linalg.norm(quat, axis=1, keepdims=True)
+  qpos[:, 2] = height
+  qvel = 0.3*rs.randn(nenv, m.nv)
+  return qpos, qvel
+
+
+def _teacher_forced(m, hb, qpos, qvel, steps, rs, W):
+  om = oracle.OracleModel(m)
+  datas = [oracle.OracleData(om) for _ in range(len(qpos))]
+  for i, d in enumerate(datas):
+    d.qpos[:] = qpos[i]
+    d.qvel[:] = qvel[i]
+    d.step1()
+  errs, rows = [], 0
+  for _ in range(steps):
+    oq = np.array([d.qpos.copy() for d in datas])
+    ov = np.array([d.qvel.copy() for d in datas])
+    ow = np.array([d.qacc_warmstart.copy() for d in datas])
+    hb.set_state(oq.T, ov.T, ow.T)
+    ctrl = rs.uniform(-1, 1, (len(qpos), m.nu))
+    hb.step_host(ctrl, 1)
+    q = hb.read(W.FIELD_QPOS).T.astype(np.float64)
+    v = hb.read(W.FIELD_QVEL).T.astype(np.float64)
+    for i, d in enumerate(datas):
+      d.ctrl[:] = ctrl[i]
+      rows += d.nefc
+      d.physics_step()
+    nq = np.array([d.qpos.copy() for d in datas])
+    nv = np.array([d.qvel.copy() for d in datas])
+    errs.append(np.maximum(helpers.rel_err(q, nq), helpers.rel_err(v, nv)))
+  return np.concatenate(errs), rows
+
+
+@pytest.mark.gpu
+def test_walker_scene_on_device_matches_oracle():
+  """62-dof position-controlled walker on the several-lanes-per-env kernel.
+  fp64: the working set of this model only fits in LDS with room for four
+  contacts, so the tight comparison runs on airborne and toe-touching poses
+  (joint limits, affine actuators with force clipping, stiff joints, 62-dof
+  CRBA / RNE / Cholesky); fp32 at full capacity from standing and lying poses."""
+  from dm_control_amd import build, wrapper as W
+  m = _walker_model()
+  rs = np.random.RandomState(0)
+  hm = W.HipModel(build.build_model(m, 0, 'f64', mode='coop', ncon_max=4))
+  hb = W.HipBatch(hm, 16)
+  qpos, qvel = _states(m, 16, rs, height=1.6)
+  qpos[8:, 2] = 1.13                          # toes at the floor
+  e, rows = _teacher_forced(m, hb, qpos, qvel, 8, rs, W)
+  assert rows > 16*8*3                        # limit rows (and a few contacts) in play
+  assert not hb.read(W.FIELD_WARN).any()
+  assert e.max() <= 1e-9, e.max()
+  hb.free()
+  hm = W.HipModel(build.build_model(m, 0, 'f32', mode='coop'))
+  hb = W.HipBatch(hm, 32)
+  qpos, qvel = _states(m, 32, rs, height=1.05)
+  qpos[16:, 2] = 0.25                         # lying / crouching in the floor
+  e, rows = _teacher_forced(m, hb, qpos, qvel, 8, rs, W)
+  print('OBSERVED fp32 per-step soccer walker: median %.2e p99 %.2e max %.2e'
+        % (np.median(e), np.percentile(e, 99), e.max()))
+  assert np.median(e) <= 2e-5 and np.percentile(e, 99) <= 2e-3
+  # soak: 300 steps of random position targets, no warnings, finite
+  for _ in range(300):
+    hb.step_host(rs.uniform(-1, 1, (32, m.nu)), 1)
+  assert not hb.read(W.FIELD_WARN).any()
+  assert np.isfinite(hb.read(W.FIELD_QPOS)).all()
+  hb.free()
+
+
+@pytest.mark.gpu
+def test_ball_scene_on_device_matches_oracle():
+  from dm_control_amd import build, wrapper as W
+  m = _ball_model()
+  rs = np.random.RandomState(1)
+  n = 64
+  qpos = np.tile(m.qpos0, (n, 1))
+  qpos[:, 2] = soccer.BALL['radius'] + rs.uniform(-0.003, 0.05, n)
+  qpos[:, :2] = rs.uniform(-5, 5, (n, 2))
+  qpos[::4, 0] = soccer.PITCH_SIZE[0] - soccer.BALL['radius'] + 0.001      # at a wall
+  quat = rs.randn(n, 4)
+  qpos[:, 3:7] = quat/np.linalg.norm(quat, axis=1, keepdims=True)
+  qvel = rs.randn(n, 6)*[3, 3, 1, 5, 5, 5]
+  hm = W.HipModel(build.build_model(m, 0, 'f64'))
+  hb = W.HipBatch(hm, n)
+  e, rows = _teacher_forced(m, hb, qpos, qvel, 12, rs, W)
+  assert rows > 100*10//2                     # ten rows per ball contact
+  assert not hb.read(W.FIELD_WARN).any()
+  assert e.max() <= 1e-9, e.max()
+  hb.free()
