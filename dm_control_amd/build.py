@@ -25,6 +25,19 @@ def _hipcc():
   return exe
 
 
+def backend():
+  """How model code objects are built: "hipcc" (the toolchain's driver, what
+  `__graft_entry__.build()` uses ahead of time) or "hiprtc" -- in-process
+  through `dmc_model_compile` of the C ABI (HIP runtime compilation: needs the
+  ROCm runtime only, no hipcc executable).  `$DMC_BUILD_BACKEND` selects;
+  default: hipcc when it exists, else hiprtc."""
+  choice = os.environ.get('DMC_BUILD_BACKEND')
+  if choice in ('hipcc', 'hiprtc'):
+    return choice
+  exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+  return 'hipcc' if os.path.exists(exe) else 'hiprtc'
+
+
 def _newer(target, sources):
   if not os.path.exists(target):
     return False
@@ -115,19 +128,26 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
   #   (cheetah: 25.4 k -> 18.6 k VALU instructions per step).  Values are
   #   unchanged for finite inputs; NaN/inf detection is done on bit patterns
   #   (`bad()` in the kernel source), not with comparisons.
-  cmd = [_hipcc(), '--genco', '--offload-arch=' + ARCH, '-O3', '-std=c++17',
-         '-ffinite-math-only', '-fno-signed-zeros',
-         '-Rpass-analysis=kernel-resource-usage',
-         '-mllvm', '-pragma-unroll-threshold=%s' % os.environ.get(
-             'DMC_PRAGMA_UNROLL_THRESHOLD', '10000000'), '-fno-slp-vectorize',
-         '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast',
-         '-DDMC_MODEL_HEADER="%s"' % header, '-I', _CSRC,
-         '-o', out + '.tmp', os.path.join(_CSRC, source)]
-  cmd[1:1] = list(extra_flags)
-  if precision == 'f64':
-    cmd.insert(1, '-DDMC_REAL_IS_DOUBLE')
-  else:
-    cmd.insert(1, '-fno-hip-fp32-correctly-rounded-divide-sqrt')
+  flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17',
+           '-ffinite-math-only', '-fno-signed-zeros',
+           '-Rpass-analysis=kernel-resource-usage',
+           '-mllvm', '-pragma-unroll-threshold=%s' % os.environ.get(
+               'DMC_PRAGMA_UNROLL_THRESHOLD', '10000000'), '-fno-slp-vectorize',
+           '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast']
+  flags[0:0] = list(extra_flags)
+  flags.insert(0, '-DDMC_REAL_IS_DOUBLE' if precision == 'f64'
+               else '-fno-hip-fp32-correctly-rounded-divide-sqrt')
+  if backend() == 'hiprtc':
+    with open(header) as f:
+      code, log = _compile_in_process(f.read(), source, flags)
+    with open(out + '.tmp', 'wb') as f:
+      f.write(code)
+    if keep_temps:
+      print(log)
+    return _spills(log, kernel)
+  cmd = [_hipcc(), '--genco'] + flags + [
+      '-DDMC_MODEL_HEADER="%s"' % header, '-I', _CSRC,
+      '-o', out + '.tmp', os.path.join(_CSRC, source)]
   if keep_temps:
     cmd.insert(1, '-save-temps')
   proc = subprocess.run(cmd, cwd=_BUILD, stdout=subprocess.PIPE,
@@ -138,6 +158,42 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
   if keep_temps:
     print(proc.stdout)
   return _spills(proc.stdout, kernel)
+
+
+def _compile_in_process(header_text, source, flags):
+  """No toolchain driver: the C ABI compiles the same source with the same
+  flags in-process (`dmc_model_compile`, HIP runtime compilation); the headers
+  travel as text."""
+  from dm_control_amd import wrapper
+  headers = {'model.h': header_text}
+  for name in ('dmc_args.h', 'dmc_kernels.hip'):
+    if name != source:
+      with open(os.path.join(_CSRC, name)) as f:
+        headers[name] = f.read()
+  with open(os.path.join(_CSRC, source)) as f:
+    text = f.read()
+  return wrapper.compile_code_object(
+      text, source, headers, list(flags) + ['-DDMC_MODEL_HEADER="model.h"'])
+
+
+def code_object_bytes(model, task=codegen.TASK_NONE, precision='f32',
+                      ncon_max=None, unroll=False, coop_group=None):
+  """gfx950 code object of `model` as bytes, built in-process (no hipcc, no
+  files): the `mj_loadXML` route for a model that was not pre-built --
+  `wrapper.HipModel.from_code(build.code_object_bytes(model))`.  The generic
+  (rolled) build by default: it compiles in seconds for any model size."""
+  flags = ['-DDMC_REAL_IS_DOUBLE' if precision == 'f64'
+           else '-fno-hip-fp32-correctly-rounded-divide-sqrt',
+           '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-ffinite-math-only',
+           '-fno-signed-zeros', '-mllvm', '-pragma-unroll-threshold=10000000',
+           '-fno-slp-vectorize',
+           '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast']
+  source = 'dmc_kernels.hip'
+  if coop_group:
+    flags.append('-DDMC_GROUP=%d' % coop_group)
+    source, unroll = 'dmc_coop.hip', True
+  header = codegen.generate_header(model, task, ncon_max, unroll=unroll)
+  return _compile_in_process(header, source, flags)[0]
 
 
 def lds_budget_for(nenv):

@@ -11,6 +11,9 @@
 #include "../../include/dmc_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -143,8 +146,120 @@ int dmc_device_count(void) {
   return n;
 }
 
+namespace {
+
+// shared by dmc_model_load (file) and dmc_model_load_data (memory image)
+int load_model(const char* path, const void* image, int device_id, dmc_model** out);
+
+// libhiprtc is opened on first use, so that the library loads (and every other
+// entry point works) on systems without it
+struct Hiprtc {
+  void* lib = nullptr;
+  decltype(&hiprtcCreateProgram) create = nullptr;
+  decltype(&hiprtcCompileProgram) compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+  decltype(&hiprtcGetProgramLog) log = nullptr;
+  decltype(&hiprtcGetCodeSize) code_size = nullptr;
+  decltype(&hiprtcGetCode) code = nullptr;
+  decltype(&hiprtcDestroyProgram) destroy = nullptr;
+  decltype(&hiprtcGetErrorString) error_string = nullptr;
+};
+
+const Hiprtc* hiprtc() {
+  static Hiprtc rtc;
+  static bool tried = false;
+  if (tried) return rtc.lib ? &rtc : nullptr;
+  tried = true;
+  for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+    rtc.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (rtc.lib) break;
+  }
+  if (!rtc.lib) return nullptr;
+#define DMC_SYM(field, symbol)                                              \
+  rtc.field = (decltype(rtc.field))dlsym(rtc.lib, #symbol);                  \
+  if (!rtc.field) { dlclose(rtc.lib); rtc.lib = nullptr; return nullptr; }
+  DMC_SYM(create, hiprtcCreateProgram)
+  DMC_SYM(compile, hiprtcCompileProgram)
+  DMC_SYM(log_size, hiprtcGetProgramLogSize)
+  DMC_SYM(log, hiprtcGetProgramLog)
+  DMC_SYM(code_size, hiprtcGetCodeSize)
+  DMC_SYM(code, hiprtcGetCode)
+  DMC_SYM(destroy, hiprtcDestroyProgram)
+  DMC_SYM(error_string, hiprtcGetErrorString)
+#undef DMC_SYM
+  return &rtc;
+}
+
+}  // namespace
+
+int dmc_model_compile(const char* source, const char* source_name,
+                      const char* const* header_names,
+                      const char* const* header_texts, int nheaders,
+                      const char* const* options, int noptions,
+                      void** code, size_t* code_size, char* log, size_t log_size) {
+  if (log && log_size) log[0] = 0;
+  if (!source || !code || !code_size || nheaders < 0 || noptions < 0 ||
+      (nheaders && (!header_names || !header_texts)) || (noptions && !options))
+    return fail("dmc_model_compile: bad argument");
+  *code = nullptr;
+  *code_size = 0;
+  const Hiprtc* rtc = hiprtc();
+  if (!rtc)
+    return fail("dmc_model_compile: the HIP runtime-compilation library "
+                "(libhiprtc) is not available: %s", dlerror() ? dlerror() : "symbols missing");
+  hiprtcProgram prog = nullptr;
+  hiprtcResult rc = rtc->create(&prog, source, source_name ? source_name : "dmc_model.hip",
+                                nheaders, const_cast<const char**>(header_texts),
+                                const_cast<const char**>(header_names));
+  if (rc != HIPRTC_SUCCESS)
+    return fail("hiprtcCreateProgram failed: %s", rtc->error_string(rc));
+  rc = rtc->compile(prog, noptions, const_cast<const char**>(options));
+  size_t n = 0;
+  if (log && log_size && rtc->log_size(prog, &n) == HIPRTC_SUCCESS && n > 1) {
+    std::vector<char> text(n + 1, 0);
+    if (rtc->log(prog, text.data()) == HIPRTC_SUCCESS) {
+      // keep the END of a long log: that is where the errors are
+      const size_t keep = n < log_size ? n : log_size - 1;
+      memcpy(log, text.data() + (n - keep), keep);
+      log[keep] = 0;
+    }
+  }
+  if (rc != HIPRTC_SUCCESS) {
+    rtc->destroy(&prog);
+    return fail("hiprtcCompileProgram failed: %s (see the log)", rtc->error_string(rc));
+  }
+  size_t size = 0;
+  rc = rtc->code_size(prog, &size);
+  void* buf = (rc == HIPRTC_SUCCESS && size) ? malloc(size) : nullptr;
+  if (buf) rc = rtc->code(prog, (char*)buf);
+  rtc->destroy(&prog);
+  if (!buf || rc != HIPRTC_SUCCESS) {
+    free(buf);
+    return fail("hiprtcGetCode failed: %s", rtc->error_string(rc));
+  }
+  *code = buf;
+  *code_size = size;
+  return 0;
+}
+
+void dmc_code_free(void* code) { free(code); }
+
 int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   if (!path || !out) return fail("dmc_model_load: null argument");
+  return load_model(path, nullptr, device_id, out);
+}
+
+int dmc_model_load_data(const void* code, size_t code_size, int device_id,
+                        dmc_model** out) {
+  if (!code || !code_size || !out) return fail("dmc_model_load_data: null argument");
+  return load_model("<memory image>", code, device_id, out);
+}
+
+}  // extern "C"
+
+namespace {
+
+int load_model(const char* path, const void* image, int device_id, dmc_model** out) {
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -157,7 +272,8 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   dmc_model* m = new (std::nothrow) dmc_model;
   if (!m) return fail("out of host memory");
   m->device = device_id;
-  hipError_t err = hipModuleLoad(&m->module, path);
+  hipError_t err = image ? hipModuleLoadData(&m->module, image)
+                         : hipModuleLoad(&m->module, path);
   if (err != hipSuccess) {
     delete m;
     (void)hipGetLastError();   // clear the runtime's sticky last-error
@@ -200,6 +316,10 @@ int dmc_model_load(const char* path, int device_id, dmc_model** out) {
   *out = m;
   return 0;
 }
+
+}  // namespace
+
+extern "C" {
 
 int dmc_model_get_info(const dmc_model* model, dmc_model_info* info) {
   if (!model || !info) return fail("dmc_model_get_info: null argument");

@@ -26,10 +26,17 @@
 // `real` is float (default) or double (-DDMC_REAL_IS_DOUBLE) -- the fp64 build
 // is the tight-parity mode, the fp32 build is the throughput mode.
 
+#if defined(__HIPCC_RTC__)
+// in-process build (dmc_model_compile, HIP runtime compilation): the device
+// runtime is built in, system headers are not available
+typedef unsigned int uint32_t;
+typedef unsigned long long uint64_t;
+#else
 #ifndef DMC_HOST_SHIM
 #include <hip/hip_runtime.h>
 #endif
 #include <stdint.h>
+#endif
 
 #ifdef DMC_REAL_IS_DOUBLE
 typedef double real;   // must match dmc_real in the generated header
@@ -1014,6 +1021,48 @@ DEV int collide_pair(const real* G, int p, RawCon* rc) {
   }
   if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE)
     return sphere_sphere(rc, margin, p1, p2, s1[0], s2[0]);
+  if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) {
+    // sphere centre clamped to the box in the box frame; with the centre inside
+    // the box the nearest face decides; normal from the sphere towards the box
+    real loc[3], nl[3], pl[3], len = 0, dist;
+    bool inside = true;
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      loc[k] = -(m2[k]*dif[0] + m2[3 + k]*dif[1] + m2[6 + k]*dif[2]);   // R2^T (p1 - p2)
+      const real cl = clampr(loc[k], -s2[k], s2[k]);
+      nl[k] = loc[k] - cl;
+      inside = inside && nl[k] == 0;
+      len += nl[k]*nl[k];
+      pl[k] = cl;
+    }
+    len = sqrt(len);
+    if (!inside && len >= DMC_MINVAL) {
+      dist = len - s1[0];
+      if (dist > margin) return 0;
+      DMC_UNROLL
+      for (int k = 0; k < 3; k++) { nl[k] /= len; pl[k] += nl[k]*R(0.5)*dist; }
+    } else {
+      int best = 0;
+      real depth = s2[0] - fabs(loc[0]);
+      DMC_UNROLL
+      for (int k = 1; k < 3; k++)
+        if (s2[k] - fabs(loc[k]) < depth) { depth = s2[k] - fabs(loc[k]); best = k; }
+      DMC_UNROLL
+      for (int k = 0; k < 3; k++) {
+        nl[k] = k == best ? (loc[k] < 0 ? R(-1) : R(1)) : R(0);
+        pl[k] = loc[k] + nl[k]*R(0.5)*(depth - s1[0]);
+      }
+      dist = -depth - s1[0];
+    }
+    rc->dist = dist;
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      rc->pos[k] = p2[k] + m2[3*k]*pl[0] + m2[3*k + 1]*pl[1] + m2[3*k + 2]*pl[2];
+      rc->frame[k] = -(m2[3*k]*nl[0] + m2[3*k + 1]*nl[1] + m2[3*k + 2]*nl[2]);
+      rc->frame[3 + k] = 0;
+    }
+    return 1;
+  }
   if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) {
     const real ax[3] = {m2[2], m2[5], m2[8]};
     real v[3], q[3];

@@ -45,6 +45,12 @@ SIGNATURES = {
     'dmc_last_error': (ctypes.c_char_p, []),
     'dmc_device_count': (_ci, []),
     'dmc_model_load': (_ci, [ctypes.c_char_p, _ci, ctypes.POINTER(_vp)]),
+    'dmc_model_compile': (_ci, [
+        ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p),
+        ctypes.POINTER(ctypes.c_char_p), _ci, ctypes.POINTER(ctypes.c_char_p), _ci,
+        ctypes.POINTER(_vp), ctypes.POINTER(_cs), ctypes.c_char_p, _cs]),
+    'dmc_code_free': (None, [_vp]),
+    'dmc_model_load_data': (_ci, [_vp, _cs, _ci, ctypes.POINTER(_vp)]),
     'dmc_model_get_info': (_ci, [_vp, ctypes.POINTER(ModelInfo)]),
     'dmc_model_free': (None, [_vp]),
     'dmc_batch_create': (_ci, [_vp, _ci, ctypes.POINTER(_vp)]),
@@ -115,18 +121,54 @@ def _check(rc):
     raise Error(get_lib().dmc_last_error().decode('utf-8', 'replace'))
 
 
+def compile_code_object(source, source_name, headers, options):
+  """gfx950 code object (bytes) of `source` built in-process by
+  `dmc_model_compile` -- HIP runtime compilation, no hipcc executable.
+
+  headers: {include name: text}; options: compiler flags.  Needs no GPU."""
+  lib = get_lib()
+  names = list(headers)
+  arr = ctypes.c_char_p*max(1, len(names))
+  hn = arr(*[n.encode() for n in names])
+  ht = arr(*[headers[n].encode() for n in names])
+  opts = (ctypes.c_char_p*max(1, len(options)))(*[o.encode() for o in options])
+  code, size = _vp(), _cs()
+  log = ctypes.create_string_buffer(1 << 16)
+  rc = lib.dmc_model_compile(source.encode(), source_name.encode(), hn, ht, len(names),
+                             opts, len(options), ctypes.byref(code),
+                             ctypes.byref(size), log, len(log))
+  if rc != 0:
+    raise Error('%s\n%s' % (lib.dmc_last_error().decode('utf-8', 'replace'),
+                            log.value.decode('utf-8', 'replace')[-4000:]))
+  try:
+    return ctypes.string_at(code.value, size.value), log.value.decode('utf-8', 'replace')
+  finally:
+    lib.dmc_code_free(code)
+
+
 class HipModel:
   """Loaded code object of one compiled model (cf. `MjModel`)."""
 
-  def __init__(self, code_object_path, device_id=0):
+  def __init__(self, code_object_path, device_id=0, code=None):
     self._lib = get_lib()
     self.ptr = _vp()
-    _check(self._lib.dmc_model_load(code_object_path.encode(), device_id,
-                                    ctypes.byref(self.ptr)))
+    if code is not None:
+      self._code = bytes(code)     # (the module keeps no reference to the image)
+      _check(self._lib.dmc_model_load_data(self._code, len(self._code), device_id,
+                                           ctypes.byref(self.ptr)))
+    else:
+      _check(self._lib.dmc_model_load(code_object_path.encode(), device_id,
+                                      ctypes.byref(self.ptr)))
     self.info = ModelInfo()
     _check(self._lib.dmc_model_get_info(self.ptr, ctypes.byref(self.info)))
     self.device_id = device_id
     self.dtype = np.float32 if self.info.real_size == 4 else np.float64
+
+  @classmethod
+  def from_code(cls, code, device_id=0):
+    """Loads a code object held in memory (`build.code_object_bytes`,
+    `dmc_model_compile`) -- no file involved."""
+    return cls(None, device_id, code=code)
 
   def free(self):
     if self.ptr:

@@ -14,7 +14,8 @@
  *   reference call (file:line)                          this ABI
  *   --------------------------------------------------  ----------------------
  *   mj_version            wrapper/core.py:65            dmc_version
- *   mj_loadXML            wrapper/core.py:312-328       dmc_model_load (*)
+ *   mj_loadXML            wrapper/core.py:312-328       dmc_model_compile /
+ *                                                       dmc_model_load (*)
  *   mj_deleteModel        wrapper/core.py:326           dmc_model_free
  *   mj_makeData           wrapper/core.py:646           dmc_batch_create
  *   mj_deleteData         wrapper/core.py:649           dmc_batch_free
@@ -29,8 +30,10 @@
  *   mj_copyData           engine.py:262                 dmc_batch_copy_state
  *
  * (*) MJCF parsing/compilation is host logic in Python
- *     (dm_control_amd/mjcf/compiler.py); what crosses the ABI is the gfx950
- *     code object specialised for that model (dm_control_amd/codegen.py).
+ *     (dm_control_amd/mjcf/compiler.py); what crosses the ABI is the model as a
+ *     table of constants (dm_control_amd/codegen.py) -- either already built
+ *     into a gfx950 code object (dmc_model_load) or as text that
+ *     dmc_model_compile turns into one in-process, without the hipcc toolchain.
  */
 #ifndef DMC_HIP_H_
 #define DMC_HIP_H_
@@ -91,6 +94,24 @@ int dmc_device_count(void);
 
 /* model = gfx950 code object specialised for one compiled MJCF */
 int dmc_model_load(const char* code_object_path, int device_id, dmc_model** out);
+/* The compile half of mj_loadXML (wrapper/core.py:312-328) at the C boundary,
+ * for a model that was not pre-built: `source` (the text of csrc/dmc_kernels.hip
+ * or csrc/dmc_coop.hip) is compiled for gfx950 against `nheaders` in-memory
+ * headers -- the generated model constants and the sources' own includes, each
+ * under the name it is #included by -- with the given compiler options, through
+ * the HIP runtime-compilation library of the ROCm runtime (libhiprtc, opened on
+ * first use): no hipcc executable, no files.  The code object is returned in a
+ * buffer owned by the library (dmc_code_free); load it with dmc_model_load_data
+ * and/or store it.  On failure the compiler log is copied into `log` (like the
+ * `char error[1000]` of mj_loadXML). */
+int dmc_model_compile(const char* source, const char* source_name,
+                      const char* const* header_names,
+                      const char* const* header_texts, int nheaders,
+                      const char* const* options, int noptions,
+                      void** code, size_t* code_size, char* log, size_t log_size);
+void dmc_code_free(void* code);
+int dmc_model_load_data(const void* code, size_t code_size, int device_id,
+                        dmc_model** out);
 int dmc_model_get_info(const dmc_model* model, dmc_model_info* info);
 void dmc_model_free(dmc_model* model);
 

@@ -686,6 +686,47 @@ static int plane_box(RawCon* c, double margin, const double* ppos,
   }
   return cnt;
 }
+/* sphere - box (MuJoCo's mjc_SphereBox, restated from its documentation of the
+ * box primitives): the sphere centre is taken into the box frame and clamped
+ * to the box; outside, the contact joins the clamped point and the sphere;
+ * with the centre inside the box the nearest face decides.  Normal: from the
+ * sphere (geom 1) towards the box (geom 2). */
+static int sphere_box(RawCon* c, double margin, const double* spos, double r,
+                      const double* bpos, const double* bmat, const double* size) {
+  double dif[3], loc[3], clamped[3], delta[3], nl[3], pl[3], dist, len = 0;
+  int k, inside = 1;
+  for (k = 0; k < 3; k++) dif[k] = spos[k] - bpos[k];
+  for (k = 0; k < 3; k++)   /* loc = R^T dif */
+    loc[k] = bmat[k]*dif[0] + bmat[3 + k]*dif[1] + bmat[6 + k]*dif[2];
+  for (k = 0; k < 3; k++) {
+    clamped[k] = loc[k] < -size[k] ? -size[k] : (loc[k] > size[k] ? size[k] : loc[k]);
+    delta[k] = loc[k] - clamped[k];
+    if (delta[k] != 0) inside = 0;
+    len += delta[k]*delta[k];
+  }
+  len = sqrt(len);
+  if (!inside && len >= MINVAL) {
+    dist = len - r;
+    if (dist > margin) return 0;
+    for (k = 0; k < 3; k++) { nl[k] = delta[k]/len; pl[k] = clamped[k] + nl[k]*0.5*dist; }
+  } else {
+    int best = 0;
+    double depth = size[0] - fabs(loc[0]);
+    for (k = 1; k < 3; k++)
+      if (size[k] - fabs(loc[k]) < depth) { depth = size[k] - fabs(loc[k]); best = k; }
+    nl[0] = nl[1] = nl[2] = 0;
+    nl[best] = loc[best] < 0 ? -1 : 1;
+    dist = -depth - r;
+    for (k = 0; k < 3; k++) pl[k] = loc[k] + nl[k]*0.5*(depth - r);
+  }
+  c->dist = dist;
+  memset(c->frame, 0, sizeof c->frame);
+  for (k = 0; k < 3; k++) {   /* world: R pl + bpos; normal sphere -> box = -R nl */
+    c->pos[k] = bpos[k] + bmat[3*k]*pl[0] + bmat[3*k + 1]*pl[1] + bmat[3*k + 2]*pl[2];
+    c->frame[k] = -(bmat[3*k]*nl[0] + bmat[3*k + 1]*nl[1] + bmat[3*k + 2]*nl[2]);
+  }
+  return 1;
+}
 static int sphere_capsule(RawCon* c, double margin, const double* spos,
                           double r, const double* cpos, const double* cmat,
                           const double* size) {
@@ -811,6 +852,8 @@ static void mjo_collision(const mjoModel* m, mjoData* d) {
         n = sphere_capsule(rc, margin, p1, s1[0], p2, m2, s2);
       else if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE)
         n = capsule_capsule(rc, margin, p1, m1, s1, p2, m2, s2);
+      else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX)
+        n = sphere_box(rc, margin, p1, s1[0], p2, m2, s2);
       else
         continue; /* pair types rejected at compile time by the host */
       for (i = 0; i < n; i++) {

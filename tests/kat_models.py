@@ -111,11 +111,47 @@ PRIMITIVES = """
 </mujoco>
 """
 
+# sphere - box: balls dropped onto / rolling against fixed boxes (the soccer
+# field box is made of such boxes and only the ball touches it,
+# locomotion/soccer/pitch.py:104-145, 565-570)
+BALLS_AND_BOXES = """
+<mujoco>
+  <option timestep="0.002"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="3 3 .1"/>
+    <geom name="block" type="box" size=".3 .2 .1" pos="0 0 .1" euler="0 0 25"/>
+    <geom name="ramp" type="box" size=".4 .3 .02" pos=".9 0 .15" euler="0 20 0"/>
+    <body name="a" pos="0.05 0.02 .45">
+      <freejoint/>
+      <geom name="a" type="sphere" size=".1" condim="6" priority="1" friction=".7 .05 .05"/>
+    </body>
+    <body name="b" pos=".85 .05 .5">
+      <freejoint/>
+      <geom name="b" type="sphere" size=".08"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+BALL_NEAR_BOX = """
+<mujoco>
+  <option gravity="0 0 0"/>
+  <worldbody>
+    <geom name="box" type="box" size=".3 .2 .1" pos=".1 -.2 .3" euler="20 35 50" margin="5"/>
+    <body name="a" pos="0 0 1">
+      <freejoint/>
+      <geom name="a" type="sphere" size="0.07" margin="5"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
 GPU_MODELS = {
     'readme_box': README_BOX,
     'box_on_floor': BOX_ON_FLOOR,
     'ball_on_floor': BALL_ON_FLOOR,
     'primitives': PRIMITIVES,
+    'balls_and_boxes': BALLS_AND_BOXES,
 }
 
 # K2 with its sensor (wrapper/core_test.py:329-344): the touch site covers the cube

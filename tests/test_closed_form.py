@@ -334,6 +334,58 @@ def test_capsule_narrowphase_against_brute_force():
       np.testing.assert_allclose(p.data.contact(i)['frame'][0], [0, 0, 1], atol=1e-12)
 
 
+def test_sphere_box_narrowphase_against_brute_force():
+  """Oracle contact of a sphere and an oriented box (outside near faces, edges
+  and corners, and with the centre inside the box) vs dense sampling of the box
+  surface; the device runs sphere-box scenes in
+  test_known_answer_models_on_device[balls_and_boxes]."""
+  rs = np.random.RandomState(1)
+  m = compiler.from_xml_string(kat_models.BALL_NEAR_BOX)
+  p = oracle.OraclePhysics(m)
+  box = m.name2id('box', 'geom')
+  size = m.geom_size[box]
+  g = np.linspace(-1, 1, 161)
+  u, v = np.meshgrid(g, g)
+  faces = []
+  for axis in range(3):
+    for sign in (-1, 1):
+      pts = np.zeros(u.shape + (3,))
+      pts[..., axis] = sign*size[axis]
+      pts[..., (axis + 1) % 3] = u*size[(axis + 1) % 3]
+      pts[..., (axis + 2) % 3] = v*size[(axis + 2) % 3]
+      faces.append(pts.reshape(-1, 3))
+  surface = np.concatenate(faces)
+  inside_seen = 0
+  for trial in range(80):
+    p.reset()
+    p.forward()
+    bpos, bmat = p.data.geom_xpos[box].copy(), p.data.geom_xmat[box].reshape(3, 3).copy()
+    if trial % 4 == 0:     # centre inside the box
+      loc = rs.uniform(-0.9, 0.9, 3)*size
+      inside_seen += 1
+    else:
+      loc = rs.uniform(-2, 2, 3)*size + rs.uniform(-0.1, 0.1, 3)
+    centre = bpos + bmat @ loc
+    p.data.qpos[:3] = centre
+    p.forward()
+    assert p.data.ncon == 1
+    con = p.data.contact(0)
+    world = bpos + surface @ bmat.T
+    d = np.linalg.norm(world - centre, axis=1)
+    k = int(np.argmin(d))
+    is_inside = np.all(np.abs(loc) < size)
+    want = (-d[k] if is_inside else d[k]) - 0.07
+    # (the nearest grid point is off by up to ~0.7 grid spacings when the centre
+    # sits on the surface, by spacing^2/(2 d) at distance d)
+    spacing = 2*max(size)/160
+    assert abs(con['dist'] - want) < 0.75*spacing, (trial, con['dist'], want)
+    towards_box = (world[k] - centre)/d[k]
+    if d[k] > 0.15:      # (far enough for the sampling grid to resolve the direction)
+      cosang = np.dot(con['frame'][0], towards_box if not is_inside else -towards_box)
+      assert cosang > 1 - 1e-3, (trial, cosang)
+  assert inside_seen == 20
+
+
 def _textbook_cartpole_rhs(state, force, ipole):
   """Cart 1 kg, pole 0.1 kg with CoM at 0.5 m, theta = 0 upright, positive theta
   tips the pole towards +x (hinge axis +y); viscous damping on both joints."""

@@ -825,6 +825,49 @@ def test_derived_frames_match_oracle():
   physics.free()
 
 
+def test_in_process_compile_and_load_from_memory(monkeypatch):
+  """`dmc_model_compile` + `dmc_model_load_data` (include/dmc_hip.h): a model
+  that was never pre-built is compiled inside the C-ABI library (HIP runtime
+  compilation, no hipcc executable, no file) and loaded from the memory image;
+  it steps like the oracle and like the toolchain-built code object.
+  `Physics.from_xml_string` takes the same route when hipcc is absent
+  (`$DMC_BUILD_BACKEND=hiprtc` here)."""
+  xml = kat_models.GPU_MODELS['primitives'].replace('size=".08"', 'size=".081"')
+  model = compiler.from_xml_string(xml)       # a model no build step has seen
+  nenv = 32
+  hm = W.HipModel.from_code(build.code_object_bytes(model, 0, 'f64'))
+  hb = W.HipBatch(hm, nenv)
+  rs = np.random.RandomState(4)
+  qpos = np.tile(model.qpos0, (nenv, 1))
+  qpos[:, 2], qpos[:, 9], qpos[:, 16] = 0.11, 0.2, 0.3
+  qpos[:, 2] += rs.uniform(0, 0.02, nenv)
+  qvel = 0.2*rs.randn(nenv, model.nv)
+  om, datas = _oracle_envs(model, qpos, qvel)
+  hb.set_state(qpos.T, qvel.T)
+  touched = False
+  for _ in range(60):
+    ctrl = rs.uniform(-1, 1, (nenv, model.nu))
+    hb.step_host(ctrl, 1)
+    for i, d in enumerate(datas):
+      d.ctrl[:] = ctrl[i]
+      d.physics_step()
+      touched |= d.ncon > 0
+  q = hb.read(W.FIELD_QPOS).T
+  assert touched
+  assert helpers.rel_err(q, np.array([d.qpos.copy() for d in datas])).max() <= 1e-6
+  hb.free()
+  # the high-level route, with the toolchain driver switched off
+  monkeypatch.setenv('DMC_BUILD_BACKEND', 'hiprtc')
+  from dm_control_amd import engine
+  physics = engine.Physics.from_xml_string(
+      xml.replace('size=".081"', 'size=".082"'), batch_size=4, precision='f32')
+  physics.reset()
+  physics.set_control(np.zeros((4, model.nu)))
+  physics.step(5)
+  assert np.isfinite(np.asarray(physics.data.qpos)).all()
+  physics.free()
+
+
 def test_c_abi_argument_errors():
   lib = wrapper.get_lib()
   model = helpers.load_model('cartpole')
