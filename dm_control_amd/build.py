@@ -190,7 +190,8 @@ def code_object_bytes(model, task=codegen.TASK_NONE, precision='f32',
            '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast']
   source = 'dmc_kernels.hip'
   if coop_group:
-    flags.append('-DDMC_GROUP=%d' % coop_group)
+    flags += ['-DDMC_GROUP=%d' % min(coop_group, 64),
+              '-DDMC_COOP_DUO=%d' % (coop_group == 128)]
     source, unroll = 'dmc_coop.hip', True
   header = codegen.generate_header(model, task, ncon_max, unroll=unroll)
   return _compile_in_process(header, source, flags)[0]
@@ -221,7 +222,7 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
   (generic loops, per-lane arrays in scratch) or "auto" (unrolled unless its
   register spills exceed MAX_*_SPILLS), or "coop": `group` lanes advance one
   env together with its working set in LDS (csrc/dmc_coop.hip; the shape for
-  nv ~ 20+ models and for small shards).  Returns the path of the gfx950 code
+  nv ~ 20+ models and for small shards; 128 = 64 lanes + a helper wavefront).  Returns the path of the gfx950 code
   object; cached in-tree by content hash.
   """
   if precision not in ('f32', 'f64', 'mixed'):
@@ -245,9 +246,12 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     # several lanes per env (csrc/dmc_coop.hip): working set in LDS, generic
     # loops; `lds_budget` does not apply (no row tiers)
     flags = tuple(f for f in extra_flags if not f.startswith('-DDMC_LDS_BUDGET'))
-    if group not in (8, 16, 32, 64):
-      raise ValueError('group must be 8, 16, 32 or 64 lanes per env')
-    flags += ('-DDMC_GROUP=%d' % group,)
+    if group not in (8, 16, 32, 64, 128):
+      raise ValueError('group must be 8, 16, 32, 64 or 128 (two wavefronts) lanes per env')
+    # 128: one env per 64 lanes plus a second wavefront that builds the
+    # constraint rows and factorises M + h D meanwhile (Euler models; the best
+    # shape while the batch fits the chip in one round, 4 envs per CU)
+    flags += ('-DDMC_GROUP=%d' % min(group, 64), '-DDMC_COOP_DUO=%d' % (group == 128))
     out = os.path.join(_BUILD, 'dmc_%s.hsaco' % model_key(
         model, task, precision, ncon_max, flags, True))
     if force or not os.path.exists(out):

@@ -440,6 +440,8 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   ti('body_chain', [v for c in chains for v in (c + [0]*maxchain)[:maxchain]])
   ti('dof_anc_len', [len(a) for a in ancs])
   ti('dof_anc', [v for a in ancs for v in (a + [0]*maxchain)[:maxchain]])
+  # last dof of the chain that moves the body (-1: welded to the world)
+  ti('body_lastdof', [c[0] if c else -1 for c in chains])
   # tables of the several-lanes-per-env kernel (csrc/dmc_coop.hip): bodies
   # grouped by tree depth (one lane per body, one pass per level), subtree sizes
   # (bodies are in depth-first order, so a subtree is a contiguous index range

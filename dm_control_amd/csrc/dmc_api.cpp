@@ -89,7 +89,10 @@ int launch(dmc_batch* b, hipFunction_t fn, DmcArgs& args, int group = -1) {
   // kernel, always one env per lane of a full wave.
   const dmc_model_info& mi = b->model->info;
   unsigned block = 64, per_block = 64;
-  if (group > 1) { per_block = (unsigned)mi.envs_per_block; }
+  if (group > 1) {   // several lanes per env: 64 threads, or two wavefronts per env
+    per_block = (unsigned)mi.envs_per_block;
+    block = (unsigned)(mi.lanes_per_env*mi.envs_per_block);
+  }
   else if (group == 1) { block = per_block = (unsigned)mi.envs_per_block; }
   const unsigned grid = (unsigned)((b->nenv + per_block - 1)/per_block);
   HIP_TRY(hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, 0, b->stream,

@@ -61,6 +61,22 @@ constexpr int CRW = odd_(NV + 5);
 enum { CC_DIST = 9, CC_PAIR = 10, CC_ROW = 11 };
 constexpr int CCW = 13;
 constexpr bool RK4 = INTEGRATOR != 0;
+// Two wavefronts per env (G = 64, Euler models): between the position stage and
+// the solver, wave 0 computes the mass matrix, the velocity stage, the smooth
+// forces and qacc_smooth while wave 1 builds the constraint rows (limits,
+// collision detection, contact Jacobians) -- two chains that only share
+// read-only inputs.  Everything else is wave 0's; wave 1 waits at the next
+// workgroup barrier.  Two barriers per step (`wsync`), see forward().
+#ifndef DMC_COOP_DUO
+#define DMC_COOP_DUO 0
+#endif
+constexpr bool DUO = DMC_COOP_DUO != 0 && G == 64 && !RK4;
+constexpr int NTHREADS = DUO ? 128 : 64;
+constexpr bool coop_damped() {
+  bool d = false;
+  for (int i = 0; i < NV; i++) d = d || dof_damping[i] > 0;
+  return d;
+}
 
 // word offsets of the per-env LDS region
 namespace off {
@@ -89,7 +105,10 @@ constexpr int CACC = CDOFDOT + NVX*6;
 constexpr int CFRC = CACC + NBODY*6;
 constexpr int TMP1 = CFRC + NBODY*6;
 constexpr int HH = TMP0;
-constexpr int HH_WORDS = NVX*NVP > 2*NVX*4 ? NVX*NVP : 2*NVX*4;   // solve scratch / factor panels
+#ifndef DMC_COOP_CB
+#define DMC_COOP_CB 4
+#endif
+constexpr int HH_WORDS = NVX*NVP > 2*NVX*DMC_COOP_CB ? NVX*NVP : 2*NVX*DMC_COOP_CB;   // solve scratch / factor panels
 constexpr int TMPEND = TMP1 - TMP0 > HH_WORDS ? TMP1 : TMP0 + HH_WORDS;
 constexpr int FS = TMPEND;              // qfrc_smooth
 constexpr int FC = FS + NVX;            // qfrc_constraint
@@ -99,12 +118,14 @@ constexpr int MA = QACC + NVX;
 constexpr int MV = MA + NVX;
 constexpr int GRAD = MV + NVX;
 constexpr int SEARCH = GRAD + NVX;
+constexpr int JQ = MA;                  // joint rotations of the position stage (4 per joint; the solver vectors are dead then)
 constexpr int GEOM = SEARCH + NVX;
 constexpr int CON = GEOM + NGX*12;
 constexpr int ROWS = CON + NCON_MAX*CCW;
 constexpr int SLV = ROWS + NEFC_MAX*CRW;
 constexpr int TOUCH = SLV + NBODY*3;     // touch sensor readings
-constexpr int TASKD = TOUCH + (NTOUCH > 0 ? NTOUCH : 1);   // per-instance task parameters
+constexpr int XCH = TOUCH + (NTOUCH > 0 ? NTOUCH : 1);      // nefc, ncon, warn from the row-building wave
+constexpr int TASKD = XCH + 4;          // (+ the velocity-stage flag) per-instance task parameters
 constexpr int OBSV = TASKD + NTDX;
 constexpr int Q0 = OBSV + NOBSX;        // RK4 stage storage
 constexpr int V0 = Q0 + (RK4 ? NQX : 0);
@@ -115,6 +136,11 @@ constexpr int END = DV + (RK4 ? NVX : 0);
 }  // namespace off
 // region stride: groups that share a 32-lane LDS half start G banks apart
 constexpr int ENV_WORDS = ((off::END + 31)/32)*32 + (G % 32);
+static_assert(NJX <= NVX, "joint rotations are staged in the solver vectors");
+// DUO: wave 1 factorises M + h D while wave 0 runs the solver (M is final
+// before the second barrier of forward(); the panel scratch is the geom
+// frames, dead once the contacts exist) and solves when the forces are final
+constexpr bool EULER_OFFLOAD = DUO && coop_damped() && NGX*12 >= 2*NVX*DMC_COOP_CB;
 static_assert((long long)ENV_WORDS*EPB*sizeof(real) <= 150*1024,
               "the env working set does not fit in LDS; use the one-lane kernel");
 
@@ -157,6 +183,14 @@ DEV double gbcast(double x, int src) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 #endif
+// a value the optimiser must treat as unknown at this point
+#ifndef DMC_HOST_SHIM
+DEV int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+#else
+DEV int opaque(int x) { return x; }
+#endif
+// hand-over between the two wavefronts of an env (a real workgroup barrier)
+DEV void wsync() { if (DUO) __syncthreads(); }
 // Group reductions.  Butterfly sums: every lane ends with the bitwise-identical
 // total (each stage adds the same two partial sums in both partner lanes), so
 // control flow that depends on them stays uniform inside the group.  On the
@@ -232,6 +266,22 @@ DEV int gscan(int x, int lane, int& total) {
   return v - x;
 }
 #endif
+// which lanes of the group hold `b` (bit = lane within the group)
+#ifndef DMC_HOST_SHIM
+DEV unsigned long long gballot(bool b) {
+  const unsigned long long w = __ballot(b);
+  if (G == 64) return w;
+  return (w >> ((threadIdx.x/G)*G)) & ((1ull << G) - 1);
+}
+DEV int first_bit(unsigned long long m) { return __ffsll((unsigned long long)m) - 1; }
+#else
+DEV unsigned long long gballot(bool b) {
+  unsigned long long x = b ? 1ull << (threadIdx.x % G) : 0ull;
+  for (int m = G/2; m > 0; m >>= 1) x |= gxor(x, m);
+  return x;
+}
+DEV int first_bit(unsigned long long m) { return __builtin_ctzll(m); }
+#endif
 DEV real gsum(real x) { return gsum_t(x); }
 DEV int gsum(int x) { return gsum_t(x); }
 DEV bool gany(bool b) { return gsum(b ? 1 : 0) != 0; }
@@ -265,6 +315,7 @@ enum { PH_KIN, PH_COM, PH_CRB, PH_FACM, PH_VEL, PH_SMOOTH, PH_LIMIT, PH_DETECT, 
   X(R, jnt_range, 2*NJX) X(R, jnt_margin, NJX) \
   X(R, qpos0, NQX) X(R, qpos_spring, NQX) \
   X(I, dof_bodyid, NVX) X(I, dof_jntid, NVX) X(I, dof_anc_len, NVX) X(I, dof_anc, NVX*MAXCHAIN) \
+  X(I, body_lastdof, NBODY) \
   X(R, dof_armature, NVX) X(R, dof_damping, NVX) X(R, dof_invweight0, NVX) \
   X(I, geom_bodyid, NGX) X(R, geom_pos, 3*NGX) X(R, geom_quat, 4*NGX)
 namespace tb {
@@ -285,7 +336,7 @@ template <int OFF> struct LdsTabR {
 // every lane of the workgroup takes part (call before any lane leaves)
 DEV void stage_tables() {
 #define X(kind, name, n) \
-  for (int k = threadIdx.x; k < (n); k += 64) coop_tab[tb::name##_off + k] = (real)dmc_model::name[k];
+  for (int k = threadIdx.x; k < (n); k += NTHREADS) coop_tab[tb::name##_off + k] = (real)dmc_model::name[k];
   COOP_TABLES(X)
 #undef X
   __syncthreads();
@@ -305,6 +356,7 @@ struct Coop {
   real time;
   unsigned warn;
   int ncon, nefc, iters;
+  int epoch;       // forward() calls so far (DUO: value of the velocity-stage flag)
 #ifdef DMC_COOP_PROFILE
   long long tprof[PH_N], tlast;
 #endif
@@ -312,6 +364,33 @@ struct Coop {
 #define X(kind, name, n) LdsTab##kind<tb::name##_off> name;
   COOP_TABLES(X)
 #undef X
+
+  // one-way signal between the two wavefronts of an env (DUO): an LDS word
+  // written with release and polled with acquire semantics
+#ifndef DMC_HOST_SHIM
+  __device__ void flag_write(int word, int value) {
+    __hip_atomic_store(reinterpret_cast<int*>(S + word), value, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __device__ int flag_read(int word) const {
+    return __hip_atomic_load(reinterpret_cast<const int*>(S + word), __ATOMIC_ACQUIRE,
+                             __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+#else
+  __device__ void flag_write(int word, int value) {
+    __atomic_store_n(reinterpret_cast<int*>(S + word), value, __ATOMIC_RELEASE);
+  }
+  __device__ int flag_read(int word) const {
+    return __atomic_load_n(reinterpret_cast<const int*>(S + word), __ATOMIC_ACQUIRE);
+  }
+#endif
+  __device__ static void flag_pause() {
+#ifndef DMC_HOST_SHIM
+    __builtin_amdgcn_s_sleep(2);
+#else
+    sched_yield();
+#endif
+  }
 
   // ---- cooperative dense linear algebra -----------------------------------
   // Lane (l + t*G) keeps row (l + t*G) of a symmetric NV x NV matrix in
@@ -339,7 +418,7 @@ struct Coop {
   // column k -- one LDS round trip per block instead of one broadcast per
   // (column, column) pair.  The panel buffer is the solve scratch at `panel`
   // (two halves used alternately, so one phase boundary per block suffices).
-  static constexpr int CB = 4;
+  static constexpr int CB = DMC_COOP_CB;
   __device__ int rows_chol(Rows& A, int panel) {
     int nbad = 0;
     _Pragma("unroll")
@@ -439,110 +518,146 @@ struct Coop {
   }
 
   // ---- position stage ------------------------------------------------------
-  __device__ void kin_body(int i) {
-    real xpos[3], xquat[4];
-    const int jadr = body_jntadr[i], jnum = body_jntnum[i];
-    if (jnum == 1 && jnt_type[jadr < 0 ? 0 : jadr] == JNT_FREE) {
-      const int qa = jnt_qposadr[jadr];
-      for (int k = 0; k < 3; k++) xpos[k] = S[off::QPOS + qa + k];
-      for (int k = 0; k < 4; k++) xquat[k] = S[off::QPOS + qa + 3 + k];
-      normalize4(xquat);
-      for (int k = 0; k < 3; k++) {
-        S[off::XANCHOR + 3*jadr + k] = xpos[k];
-        S[off::XAXIS + 3*jadr + k] = R(jnt_axis[3*jadr + k]);
-      }
-    } else {
-      const int pid = body_parentid[i];
-      real bp[3] = {R(body_pos[3*i]), R(body_pos[3*i + 1]), R(body_pos[3*i + 2])};
-      real bq[4] = {R(body_quat[4*i]), R(body_quat[4*i + 1]),
-                    R(body_quat[4*i + 2]), R(body_quat[4*i + 3])};
-      real pm[9], pq[4], v[3];
-      for (int k = 0; k < 9; k++) pm[k] = S[off::XMAT + 9*pid + k];
-      for (int k = 0; k < 4; k++) pq[k] = S[off::XQUAT + 4*pid + k];
-      mulmatvec3(v, pm, bp);
-      for (int k = 0; k < 3; k++) xpos[k] = S[off::XPOS + 3*pid + k] + v[k];
-      mulquat(xquat, pq, bq);
-      for (int j = 0; j < jnum; j++) {
-        const int jid = jadr + j, qa = jnt_qposadr[jid], jt = jnt_type[jid];
-        real jax[3] = {R(jnt_axis[3*jid]), R(jnt_axis[3*jid + 1]), R(jnt_axis[3*jid + 2])};
-        real jp[3] = {R(jnt_pos[3*jid]), R(jnt_pos[3*jid + 1]), R(jnt_pos[3*jid + 2])};
-        real anchor[3], axis[3];
-        rotvecquat(axis, jax, xquat);
-        rotvecquat(anchor, jp, xquat);
-        for (int k = 0; k < 3; k++) anchor[k] += xpos[k];
-        for (int k = 0; k < 3; k++) {
-          S[off::XANCHOR + 3*jid + k] = anchor[k];
-          S[off::XAXIS + 3*jid + k] = axis[k];
-        }
-        if (jt == JNT_SLIDE) {
-          const real q = S[off::QPOS + qa] - R(qpos0[qa]);
-          for (int k = 0; k < 3; k++) xpos[k] += axis[k]*q;
-        } else if (jt == JNT_HINGE || jt == JNT_BALL) {
-          real qloc[4], r[4], vec[3];
-          if (jt == JNT_BALL) {
-            for (int k = 0; k < 4; k++) qloc[k] = S[off::QPOS + qa + k];
-            normalize4(qloc);
-          } else {
-            axisangle2quat(qloc, jax, S[off::QPOS + qa] - R(qpos0[qa]));
-          }
-          mulquat(r, xquat, qloc);
-          for (int k = 0; k < 4; k++) xquat[k] = r[k];
-          rotvecquat(vec, jp, xquat);
-          for (int k = 0; k < 3; k++) xpos[k] = anchor[k] - vec[k];
-        }
-      }
-    }
-    normalize4(xquat);
-    real xm[9];
-    quat2mat(xm, xquat);
-    for (int k = 0; k < 3; k++) S[off::XPOS + 3*i + k] = xpos[k];
-    for (int k = 0; k < 4; k++) S[off::XQUAT + 4*i + k] = xquat[k];
-    for (int k = 0; k < 9; k++) S[off::XMAT + 9*i + k] = xm[k];
-    real ip[3] = {R(body_ipos[3*i]), R(body_ipos[3*i + 1]), R(body_ipos[3*i + 2])};
-    real iq[4] = {R(body_iquat[4*i]), R(body_iquat[4*i + 1]),
-                  R(body_iquat[4*i + 2]), R(body_iquat[4*i + 3])};
-    real v[3], q[4], im[9];
-    mulmatvec3(v, xm, ip);
-    for (int k = 0; k < 3; k++) S[off::XIPOS + 3*i + k] = xpos[k] + v[k];
-    mulquat(q, xquat, iq);
-    quat2mat(im, q);
-    for (int k = 0; k < 9; k++) S[off::XIMAT + 9*i + k] = im[k];
-  }
-
+  // The tree is walked once per level, and the wave waits for the slowest lane
+  // of each level -- so everything that does not depend on the parent's world
+  // frame is taken out of the walk and done in parallel first:
+  //   (1) lane = joint: the joint's own rotation quaternion (the sin/cos);
+  //   (2) lane = body:  the body's pose RELATIVE TO ITS PARENT with its joints
+  //       applied in order, and the joints' anchors and axes in that frame;
+  //   (3) level walk:   world pose = parent's world pose o relative pose;
+  //   (4) lane = joint / body: anchors, axes and inertial frames in the world.
+  // mj_kinematics composes the same transforms joint by joint in the world
+  // frame; the two orders agree to rounding.
   __device__ void kinematics() {
-    if (l == 0) {   // world body
-      for (int k = 0; k < 3; k++) { S[off::XPOS + k] = 0; S[off::XIPOS + k] = 0; }
-      S[off::XQUAT] = 1; S[off::XQUAT + 1] = S[off::XQUAT + 2] = S[off::XQUAT + 3] = 0;
-      for (int k = 0; k < 9; k++) {
-        const real v = (k == 0 || k == 4 || k == 8) ? R(1) : R(0);
-        S[off::XMAT + k] = v; S[off::XIMAT + k] = v;
+    for (int j = l; j < NJNT; j += G) {
+      const int jt = jnt_type[j], qa = jnt_qposadr[j];
+      real q[4] = {1, 0, 0, 0};
+      if (jt == JNT_HINGE) {
+        const real jax[3] = {R(jnt_axis[3*j]), R(jnt_axis[3*j + 1]), R(jnt_axis[3*j + 2])};
+        axisangle2quat(q, jax, S[off::QPOS + qa] - R(qpos0[qa]));
+      } else if (jt == JNT_BALL) {
+        for (int k = 0; k < 4; k++) q[k] = S[off::QPOS + qa + k];
+        normalize4(q);
+      } else if (jt == JNT_SLIDE) {
+        q[0] = S[off::QPOS + qa] - R(qpos0[qa]);   // displacement along the axis
       }
+      for (int k = 0; k < 4; k++) S[off::JQ + 4*j + k] = q[k];
+    }
+    gsync();
+    for (int i = l; i < NBODY; i += G) {
+      real lp[3] = {0, 0, 0}, lq[4] = {1, 0, 0, 0};
+      if (i > 0) {
+        const int jadr = body_jntadr[i], jnum = body_jntnum[i];
+        if (jnum == 1 && jnt_type[jadr < 0 ? 0 : jadr] == JNT_FREE) {
+          const int qa = jnt_qposadr[jadr];
+          for (int k = 0; k < 3; k++) lp[k] = S[off::QPOS + qa + k];
+          for (int k = 0; k < 4; k++) lq[k] = S[off::QPOS + qa + 3 + k];
+          normalize4(lq);
+          for (int k = 0; k < 3; k++) {
+            S[off::XANCHOR + 3*jadr + k] = lp[k];
+            S[off::XAXIS + 3*jadr + k] = R(jnt_axis[3*jadr + k]);
+          }
+        } else {
+          for (int k = 0; k < 3; k++) lp[k] = R(body_pos[3*i + k]);
+          for (int k = 0; k < 4; k++) lq[k] = R(body_quat[4*i + k]);
+          for (int j = 0; j < jnum; j++) {
+            const int jid = jadr + j, jt = jnt_type[jid];
+            const real jax[3] = {R(jnt_axis[3*jid]), R(jnt_axis[3*jid + 1]), R(jnt_axis[3*jid + 2])};
+            const real jp[3] = {R(jnt_pos[3*jid]), R(jnt_pos[3*jid + 1]), R(jnt_pos[3*jid + 2])};
+            real anchor[3], axis[3], m[9];
+            quat2mat(m, lq);
+            mulmatvec3(axis, m, jax);
+            mulmatvec3(anchor, m, jp);
+            for (int k = 0; k < 3; k++) anchor[k] += lp[k];
+            for (int k = 0; k < 3; k++) {
+              S[off::XANCHOR + 3*jid + k] = anchor[k];
+              S[off::XAXIS + 3*jid + k] = axis[k];
+            }
+            if (jt == JNT_SLIDE) {
+              const real q = S[off::JQ + 4*jid];
+              for (int k = 0; k < 3; k++) lp[k] += axis[k]*q;
+            } else if (jt == JNT_HINGE || jt == JNT_BALL) {
+              real qloc[4], r[4], vec[3];
+              for (int k = 0; k < 4; k++) qloc[k] = S[off::JQ + 4*jid + k];
+              mulquat(r, lq, qloc);
+              for (int k = 0; k < 4; k++) lq[k] = r[k];
+              rotvecquat(vec, jp, lq);
+              for (int k = 0; k < 3; k++) lp[k] = anchor[k] - vec[k];
+            }
+          }
+        }
+      }
+      for (int k = 0; k < 3; k++) S[off::XPOS + 3*i + k] = lp[k];
+      for (int k = 0; k < 4; k++) S[off::XQUAT + 4*i + k] = lq[k];
+      if (i == 0)
+        for (int k = 0; k < 9; k++) S[off::XMAT + k] = (k == 0 || k == 4 || k == 8) ? R(1) : R(0);
     }
     gsync();
     for (int lev = 0; lev < NLEVEL; lev++) {
-      for (int idx = level_adr[lev] + l; idx < level_adr[lev + 1]; idx += G)
-        kin_body(level_body[idx]);
+      for (int idx = level_adr[lev] + l; idx < level_adr[lev + 1]; idx += G) {
+        const int i = level_body[idx], pid = body_parentid[i];
+        real pm[9], pq[4], lp[3], lq[4], v[3], xquat[4], xm[9];
+        for (int k = 0; k < 9; k++) pm[k] = S[off::XMAT + 9*pid + k];
+        for (int k = 0; k < 4; k++) pq[k] = S[off::XQUAT + 4*pid + k];
+        for (int k = 0; k < 3; k++) lp[k] = S[off::XPOS + 3*i + k];
+        for (int k = 0; k < 4; k++) lq[k] = S[off::XQUAT + 4*i + k];
+        mulmatvec3(v, pm, lp);
+        mulquat(xquat, pq, lq);
+        normalize4(xquat);
+        quat2mat(xm, xquat);
+        for (int k = 0; k < 3; k++) S[off::XPOS + 3*i + k] = S[off::XPOS + 3*pid + k] + v[k];
+        for (int k = 0; k < 4; k++) S[off::XQUAT + 4*i + k] = xquat[k];
+        for (int k = 0; k < 9; k++) S[off::XMAT + 9*i + k] = xm[k];
+      }
       gsync();
     }
+    for (int j = l; j < NJNT; j += G) {
+      const int pid = body_parentid[jnt_bodyid[j]];
+      real pm[9], a[3], x[3], va[3], vx[3];
+      for (int k = 0; k < 9; k++) pm[k] = S[off::XMAT + 9*pid + k];
+      for (int k = 0; k < 3; k++) { a[k] = S[off::XANCHOR + 3*j + k]; x[k] = S[off::XAXIS + 3*j + k]; }
+      mulmatvec3(va, pm, a);
+      mulmatvec3(vx, pm, x);
+      for (int k = 0; k < 3; k++) {
+        S[off::XANCHOR + 3*j + k] = S[off::XPOS + 3*pid + k] + va[k];
+        S[off::XAXIS + 3*j + k] = vx[k];
+      }
+    }
+    for (int i = l; i < NBODY; i += G) {
+      real xm[9], xq[4], v[3], q[4], im[9];
+      const real ip[3] = {R(body_ipos[3*i]), R(body_ipos[3*i + 1]), R(body_ipos[3*i + 2])};
+      const real iq[4] = {R(body_iquat[4*i]), R(body_iquat[4*i + 1]),
+                          R(body_iquat[4*i + 2]), R(body_iquat[4*i + 3])};
+      for (int k = 0; k < 9; k++) xm[k] = S[off::XMAT + 9*i + k];
+      for (int k = 0; k < 4; k++) xq[k] = S[off::XQUAT + 4*i + k];
+      mulmatvec3(v, xm, ip);
+      for (int k = 0; k < 3; k++) S[off::XIPOS + 3*i + k] = S[off::XPOS + 3*i + k] + v[k];
+      mulquat(q, xq, iq);
+      quat2mat(im, q);
+      for (int k = 0; k < 9; k++) S[off::XIMAT + 9*i + k] = i == 0 ? ((k == 0 || k == 4 || k == 8) ? R(1) : R(0)) : im[k];
+    }
+    gsync();
   }
 
   __device__ void com_pos() {
     // subtree centre of mass: bodies are depth-first ordered, a subtree is the
-    // index range [i, i + body_subtree_n[i])
-    for (int i = l; i < NBODY; i += G) {
-      real acc[3] = {0, 0, 0};
+    // index range [i, i + body_subtree_n[i]).  lane = (body, axis); the range
+    // loop runs its full static length with the terms past the end masked, so
+    // all loads are in flight together (see com_vel)
+    for (int idx = l; idx < NBODY*3; idx += G) {
+      const int i = idx/3, k = idx - 3*i;
       const int n = body_subtree_n[i];
-      for (int j = i; j < i + n; j++) {
-        const real mass = R(body_mass[j]);
-        for (int k = 0; k < 3; k++) acc[k] += mass*S[off::XIPOS + 3*j + k];
+      real acc = 0;
+      _Pragma("unroll")
+      for (int jj = 0; jj < NBODY; jj++) {
+        const bool in = jj < n;
+        const int j = in ? i + jj : i;
+        const real mass = in ? R(body_mass[j]) : R(0);
+        acc += mass*S[off::XIPOS + 3*j + k];
       }
-      if (body_subtreemass[i] < 1e-15) {
-        for (int k = 0; k < 3; k++) acc[k] = S[off::XIPOS + 3*i + k];
-      } else {
-        const real inv = R(1)/R(body_subtreemass[i]);
-        for (int k = 0; k < 3; k++) acc[k] *= inv;
-      }
-      for (int k = 0; k < 3; k++) S[off::SUBCOM + 3*i + k] = acc[k];
+      if (body_subtreemass[i] < 1e-15) acc = S[off::XIPOS + idx];
+      else acc *= R(1)/R(body_subtreemass[i]);
+      S[off::SUBCOM + idx] = acc;
     }
     gsync();
     for (int i = l; i < NBODY; i += G) {
@@ -602,95 +717,115 @@ struct Coop {
 
   // composite inertias and the full symmetric mass matrix
   __device__ void crb_matrix() {
-    for (int i = l; i < NBODY; i += G) {
-      real acc[10];
-      for (int k = 0; k < 10; k++) acc[k] = 0;
-      if (i > 0) {
-        const int n = body_subtree_n[i];
-        for (int j = i; j < i + n; j++)
-          for (int k = 0; k < 10; k++) acc[k] += S[off::CINERT + 10*j + k];
+    // composite inertia = range sum of cinert over the subtree, lane = (body, word)
+    for (int idx = l; idx < NBODY*10; idx += G) {
+      const int i = idx/10, k = idx - 10*i;
+      const int n = i > 0 ? body_subtree_n[i] : 0;
+      real acc = 0;
+      _Pragma("unroll")
+      for (int jj = 0; jj < NBODY - 1; jj++) {
+        const bool in = jj < n;
+        const real v = S[off::CINERT + 10*(in ? i + jj : i) + k];
+        acc += in ? v : R(0);
       }
-      for (int k = 0; k < 10; k++) S[off::CRB + 10*i + k] = acc[k];
+      S[off::CRB + idx] = acc;
     }
-    for (int k = l; k < NV*NVP; k += G) S[off::MM + k] = 0;
     gsync();
+    // lane = dof: M[i][i] and M[i][ancestors of i]; the entries between
+    // unrelated dofs are structural zeros, written once per launch (load())
     for (int i = l; i < NV; i += G) {
       real buf[6], cd[6], crb[10];
       for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*i + k];
       for (int k = 0; k < 10; k++) crb[k] = S[off::CRB + 10*dof_bodyid[i] + k];
       mul_inert_vec(buf, crb, cd);
-      S[off::MM + i*NVP + i] = dot6(cd, buf) + R(dof_armature[i]);
       const int na = dof_anc_len[i];
-      for (int a = 0; a < na; a++) {
-        const int j = dof_anc[i*MAXCHAIN + a];
+      int anc[MAXCHAIN];
+      // (the table index is made opaque: otherwise the compiler hoists these
+      // reads and the 3*MAXCHAIN addresses derived from them out of the substep
+      // loop and keeps them live -- or spilled -- through the whole step)
+      const int row = opaque(i*MAXCHAIN);
+      _Pragma("unroll")
+      for (int a = 0; a < MAXCHAIN; a++) anc[a] = dof_anc[row + a];
+      const real diag = dot6(cd, buf) + R(dof_armature[i]);
+      _Pragma("unroll")
+      for (int a = 0; a < MAXCHAIN; a++) {
+        // branch-free: the slots past the end of the chain rewrite the diagonal
+        const int j = a < na ? anc[a] : i;
         real cj[6];
         for (int k = 0; k < 6; k++) cj[k] = S[off::CDOF + 6*j + k];
-        const real v = dot6(cj, buf);
+        const real v = a < na ? dot6(cj, buf) : diag;
         S[off::MM + i*NVP + j] = v;
         S[off::MM + j*NVP + i] = v;
       }
+      S[off::MM + i*NVP + i] = diag;
     }
     gsync();
     PROF(PH_CRB);
   }
 
   // ---- velocity stage --------------------------------------------------------
-  // body velocity, cdof_dot and the bias acceleration, one tree level per phase
-  __device__ void vel_body(int i) {
-    const int pid = body_parentid[i];
-    real cvel[6], cacc[6];
-    for (int k = 0; k < 6; k++) {
-      cvel[k] = S[off::CVEL + 6*pid + k];
-      cacc[k] = S[off::CACC + 6*pid + k];
-    }
-    const int jadr = body_jntadr[i], jnum = body_jntnum[i];
-    for (int j = 0; j < jnum; j++) {
-      const int jid = jadr + j, jt = jnt_type[jid];
-      int da = jnt_dofadr[jid];
-      if (jt == JNT_FREE || jt == JNT_BALL) {
-        if (jt == JNT_FREE) {
-          for (int k = 0; k < 18; k++) S[off::CDOFDOT + 6*da + k] = 0;
-          for (int k = 0; k < 3; k++)
-            for (int c = 0; c < 6; c++)
-              cvel[c] += S[off::CDOF + 6*(da + k) + c]*S[off::QVEL + da + k];
-          da += 3;
-        }
-        real cd[18], dd[18];
-        for (int k = 0; k < 18; k++) cd[k] = S[off::CDOF + 6*da + k];
-        for (int k = 0; k < 3; k++) cross_motion(dd + 6*k, cvel, cd + 6*k);
-        for (int k = 0; k < 18; k++) S[off::CDOFDOT + 6*da + k] = dd[k];
-        for (int k = 0; k < 3; k++) {
-          const real qv = S[off::QVEL + da + k];
-          for (int c = 0; c < 6; c++) { cvel[c] += cd[6*k + c]*qv; cacc[c] += dd[6*k + c]*qv; }
-        }
-      } else {
-        real cd[6], dd[6];
-        for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*da + k];
-        cross_motion(dd, cvel, cd);
-        const real qv = S[off::QVEL + da];
-        for (int c = 0; c < 6; c++) {
-          S[off::CDOFDOT + 6*da + c] = dd[c];
-          cvel[c] += cd[c]*qv; cacc[c] += dd[c]*qv;
-        }
-      }
-    }
-    for (int k = 0; k < 6; k++) { S[off::CVEL + 6*i + k] = cvel[k]; S[off::CACC + 6*i + k] = cacc[k]; }
-  }
+  // Body velocities, cdof_dot and the bias accelerations.  In the frame the
+  // spatial vectors use (world axes, origin at the subtree's centre of mass) a
+  // body's velocity is the plain sum of cdof*qvel over the dofs between the
+  // root and the body, so no level-by-level walk is needed:
+  //   lane = dof:  cdof_dot = velocity of everything upstream of the dof's
+  //                joint  x  cdof   (mj_comVel: cvel "before the joint");
+  //   lane = body: cvel and cacc as sums over the body's dof chain, added in
+  //                root-to-leaf order like the reference's walk.
   __device__ void com_vel() {
-    if (l == 0) {
-      for (int k = 0; k < 6; k++) { S[off::CVEL + k] = 0; S[off::CACC + k] = 0; }
-      if (!(DISABLEFLAGS & DSBL_GRAVITY))
-        for (int k = 0; k < 3; k++) S[off::CACC + 3 + k] = -R(gravity[k]);
+    // The chain loops run their full static length with the terms past the end
+    // weighted by zero: all index loads, then all data loads, are independent
+    // and in flight together instead of one LDS round trip per ancestor.
+    for (int d = l; d < NV; d += G) {
+      const int j = dof_jntid[d], jt = jnt_type[j], da = jnt_dofadr[j];
+      // dofs of the same ball / free-rotation joint do not count as upstream;
+      // the translational dofs of a free joint have cdof_dot = 0
+      const int first = jt == JNT_BALL ? da : (jt == JNT_FREE ? da + 3 : d);
+      const int na = (jt == JNT_FREE && d < da + 3) ? 0 : dof_anc_len[d];
+      int anc[MAXCHAIN];
+      const int row = opaque(d*MAXCHAIN);
+      _Pragma("unroll")
+      for (int a = 0; a < MAXCHAIN; a++) anc[a] = dof_anc[row + a];
+      real cvel[6] = {0, 0, 0, 0, 0, 0}, cd[6], dd[6];
+      _Pragma("unroll")
+      for (int a = MAXCHAIN - 1; a >= 0; a--) {
+        const int k = anc[a];
+        const real qv = (a < na && k < first) ? S[off::QVEL + k] : R(0);
+        _Pragma("unroll")
+        for (int c = 0; c < 6; c++) cvel[c] += S[off::CDOF + 6*k + c]*qv;
+      }
+      for (int c = 0; c < 6; c++) cd[c] = S[off::CDOF + 6*d + c];
+      cross_motion(dd, cvel, cd);
+      for (int c = 0; c < 6; c++) S[off::CDOFDOT + 6*d + c] = dd[c];
     }
     gsync();
-    for (int lev = 0; lev < NLEVEL; lev++) {
-      for (int idx = level_adr[lev] + l; idx < level_adr[lev + 1]; idx += G)
-        vel_body(level_body[idx]);
-      gsync();
+    for (int i = l; i < NBODY; i += G) {
+      real cvel[6] = {0, 0, 0, 0, 0, 0}, cacc[6] = {0, 0, 0, 0, 0, 0};
+      if (!(DISABLEFLAGS & DSBL_GRAVITY))
+        for (int k = 0; k < 3; k++) cacc[3 + k] = -R(gravity[k]);
+      const int last = body_lastdof[i];
+      const int lastx = last < 0 ? 0 : last;
+      const int na = last < 0 ? -1 : dof_anc_len[lastx];
+      int anc[MAXCHAIN];
+      const int row = opaque(lastx*MAXCHAIN);
+      _Pragma("unroll")
+      for (int a = 0; a < MAXCHAIN; a++) anc[a] = dof_anc[row + a];
+      _Pragma("unroll")
+      for (int a = MAXCHAIN; a >= 0; a--) {
+        const int k = a == 0 ? lastx : anc[a - 1];
+        const real qv = a <= na ? S[off::QVEL + k] : R(0);
+        _Pragma("unroll")
+        for (int c = 0; c < 6; c++) {
+          cvel[c] += S[off::CDOF + 6*k + c]*qv;
+          cacc[c] += S[off::CDOFDOT + 6*k + c]*qv;
+        }
+      }
+      for (int k = 0; k < 6; k++) { S[off::CVEL + 6*i + k] = cvel[k]; S[off::CACC + 6*i + k] = cacc[k]; }
     }
+    gsync();
   }
 
-  // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
+  // qfrc_smooth = passive - bias + actuator
   __device__ void smooth_forces(bool actuation) {
     for (int i = l; i < NBODY; i += G) {
       real f[6];
@@ -707,12 +842,26 @@ struct Coop {
       for (int k = 0; k < 6; k++) S[off::CFRC + 6*i + k] = f[k];
     }
     gsync();
-    // bias force of dof i = cdof_i . (sum of cfrc over the subtree of its body)
+    // force on the subtree of every body, lane = (body, component) (range sum
+    // as in crb_matrix; the composite inertias are dead, their words take it)
+    for (int idx = l; idx < NBODY*6; idx += G) {
+      const int i = idx/6, k = idx - 6*i;
+      const int n = body_subtree_n[i];
+      real acc = 0;
+      _Pragma("unroll")
+      for (int jj = 0; jj < NBODY; jj++) {
+        const bool in = jj < n;
+        const real v = S[off::CFRC + 6*(in ? i + jj : i) + k];
+        acc += in ? v : R(0);
+      }
+      S[off::CRB + idx] = acc;
+    }
+    gsync();
+    // bias force of dof i = cdof_i . (force on the subtree of its body)
     for (int i = l; i < NV; i += G) {
-      const int b = dof_bodyid[i], n = body_subtree_n[b];
-      real f[6] = {0, 0, 0, 0, 0, 0}, cd[6];
-      for (int j = b; j < b + n; j++)
-        for (int k = 0; k < 6; k++) f[k] += S[off::CFRC + 6*j + k];
+      const int b = dof_bodyid[i];
+      real f[6], cd[6];
+      for (int k = 0; k < 6; k++) f[k] = S[off::CRB + 6*b + k];
       for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*i + k];
       real fs = -dot6(cd, f);
       if (!(DISABLEFLAGS & DSBL_PASSIVE)) {
@@ -727,15 +876,18 @@ struct Coop {
         const EnvView V = {S + off::QPOS, S + off::QVEL, S + off::CTRL, S + off::XPOS,
                            S + off::XMAT, S + off::XIPOS, S + off::SLV, S + off::TOUCH,
                            S + off::TASKD};
+        // every lane evaluates every actuator (unrolled: all model tables fold
+        // to literals, the controls are uniform LDS reads) and keeps the ones
+        // whose transmission reaches its dof
+        _Pragma("unroll")
         for (int u = 0; u < NU; u++) {
-          // does this actuator's transmission reach dof i?
           real moment = 0;
           bool mine = false;
+          _Pragma("unroll")
           for (int k = 0; k < act_wrap_num[u]; k++) {
             const int w = act_wrap_adr[u] + k;
             if (act_wrap_dof[w] == i) { moment += wrap_coef(V, w); mine = true; }
           }
-          if (!mine) continue;
           const real gear = R(actuator_gear[u]);
           real c = S[off::CTRL + u];
           if (actuator_ctrllimited[u] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
@@ -743,6 +895,7 @@ struct Coop {
           real force = R(actuator_gainprm[3*u])*c;
           if (actuator_biastype[u] == 1) {
             real length = 0, velocity = 0;
+            _Pragma("unroll")
             for (int k = 0; k < act_wrap_num[u]; k++) {
               const int w = act_wrap_adr[u] + k;
               const real coef = wrap_coef(V, w);
@@ -754,17 +907,21 @@ struct Coop {
           }
           if (actuator_forcelimited[u])
             force = clampr(force, R(actuator_forcerange[2*u]), R(actuator_forcerange[2*u + 1]));
-          fs += gear*moment*force;
+          if (mine) fs += gear*moment*force;
         }
       }
       S[off::FS + i] = fs;
     }
     gsync();
     PROF(PH_SMOOTH);
-    Rows L;
+  }
+  // M = L L^T, and qacc_smooth = M^-1 qfrc_smooth
+  __device__ void factor_mass(Rows& L) {
     rows_load(L, off::MM);
     if (rows_chol(L, off::HH)) warn |= WARN_INERTIA;
     PROF(PH_FACM);
+  }
+  __device__ void smooth_acc(const Rows& L) {
     real b[RNV];
     _Pragma("unroll")
     for (int t = 0; t < RNV; t++) b[t] = l + t*G < NV ? S[off::FS + l + t*G] : R(0);
@@ -861,8 +1018,9 @@ struct Coop {
 
   // narrowphase over the static pair list, strided over the lanes; an ordered
   // prefix sum per stride keeps the contact list in pair order
-  __device__ void detect_contacts() {
-    if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return;
+  // returns the number of constraint rows once the contacts' rows are counted
+  __device__ int detect_contacts() {
+    if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return nefc;
     for (int g = l; g < NGEOM; g += G) {
       const int b = geom_bodyid[g];
       real gp[3] = {R(geom_pos[3*g]), R(geom_pos[3*g + 1]), R(geom_pos[3*g + 2])};
@@ -924,13 +1082,18 @@ struct Coop {
     }
     warn = gor_bits(warn);
     gsync();
+    return nrow_total;
   }
 
-  // Jacobian columns of all contact rows: lane = dof
+  // Jacobian columns of all contact rows: lane = (contact, dof), so a few
+  // simultaneous contacts cost one pass instead of one pass each.  Every lane
+  // derives its contact's frame and row parameters itself (the per-pair model
+  // tables are indexed per lane); the lane of dof 0 writes the row metadata.
   __device__ void contact_rows() {
-    detect_contacts();
+    const int rows_after = detect_contacts();
     PROF(PH_DETECT);
-    for (int c = 0; c < ncon; c++) {
+    for (int idx = l; idx < ncon*NV; idx += G) {
+      const int c = idx/NV, j = idx - c*NV;
       const real* rec = S + off::CON + c*CCW;
       const int r0 = (int)rec[CC_ROW];
       if (r0 < 0) continue;
@@ -940,55 +1103,53 @@ struct Coop {
       for (int k = 0; k < 3; k++) { pos[k] = rec[k]; fin[k] = rec[3 + k]; fin[3 + k] = rec[6 + k]; }
       make_frame(fin, f);
       const int b1 = pair_b1[p], b2 = pair_b2[p], dim = pair_dim[p];
-      const unsigned m1lo = body_dofmask_lo[b1], m2lo = body_dofmask_lo[b2];
-      const unsigned m1hi = body_dofmask_hi[b1], m2hi = body_dofmask_hi[b2];
+      const unsigned m1 = j < 32 ? body_dofmask_lo[b1] >> j : body_dofmask_hi[b1] >> (j - 32);
+      const unsigned m2 = j < 32 ? body_dofmask_lo[b2] >> j : body_dofmask_hi[b2] >> (j - 32);
+      const bool in1 = (m1 & 1u) != 0, in2 = (m2 & 1u) != 0;
       real off1[3], off2[3];
       for (int k = 0; k < 3; k++) {
         off1[k] = pos[k] - S[off::SUBCOM + 3*body_rootid[b1] + k];
         off2[k] = pos[k] - S[off::SUBCOM + 3*body_rootid[b2] + k];
       }
-      const real pm = dist - R(pair_includemargin[p]);
-      const real imp = impedance(pair_solimp + 5*p, pm);
-      const real K = R(pair_K[p]), B = R(pair_B[p]);
       const int nrow = pair_nrow[p];
-      // per-row metadata (one lane); rows past the capacity are dropped
-      const real mu0 = R(pair_friction[5*p]);
-      real R0 = (1 - imp)*R(pair_diag[6*p + 1])/imp;
-      if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
-      const real Rrow = dim == 1 ? (1 - imp)*R(pair_diag[6*p])/imp : 2*mu0*mu0*R0;
       if (r0 + nrow > NEFC_MAX) warn |= WARN_CNSTRFULL;
-      if (l == 0)
+      if (j == 0) {   // per-row metadata; rows past the capacity are dropped
+        const real pm = dist - R(pair_includemargin[p]);
+        const real imp = impedance(pair_solimp + 5*p, pm);
+        const real K = R(pair_K[p]), B = R(pair_B[p]);
+        const real mu0 = R(pair_friction[5*p]);
+        real R0 = (1 - imp)*R(pair_diag[6*p + 1])/imp;
+        if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
+        const real Rrow = dim == 1 ? (1 - imp)*R(pair_diag[6*p])/imp : 2*mu0*mu0*R0;
         for (int r = r0; r < r0 + nrow && r < NEFC_MAX; r++) row_meta(r, pm, K, B, imp, Rrow);
-      real w1[3][3], w2[3][3];
-      for (int d = 0; d < 3; d++) { cross3(w1[d], off1, f + 3*d); cross3(w2[d], off2, f + 3*d); }
-      for (int j = l; j < NV; j += G) {
-        const bool in1 = ((j < 32 ? m1lo >> j : m1hi >> (j - 32)) & 1u) != 0;
-        const bool in2 = ((j < 32 ? m2lo >> j : m2hi >> (j - 32)) & 1u) != 0;
-        real cd[6], jb[3], jt[3];
-        for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*j + k];
-        for (int d = 0; d < 3; d++) {
-          const real* dir = f + 3*d;
-          const real dl = dot3(dir, cd + 3);
-          const real v2 = dl + dot3(w2[d], cd), v1 = dl + dot3(w1[d], cd);
-          jb[d] = (in2 ? v2 : R(0)) - (in1 ? v1 : R(0));
-          const real vr = dot3(dir, cd);
-          jt[d] = (in2 ? vr : R(0)) - (in1 ? vr : R(0));
-        }
-        real* col = S + off::ROWS + j;
-        if (dim == 1) {
-          if (r0 < NEFC_MAX) col[r0*CRW] = jb[0];
-        } else {
-          for (int k = 1; k < dim; k++) {
-            const real mu = R(pair_friction[5*p + k - 1]);
-            const real t = k < 3 ? jb[k] : jt[k - 3];
-            const int r = r0 + 2*(k - 1);
-            if (r < NEFC_MAX) col[r*CRW] = jb[0] + mu*t;
-            if (r + 1 < NEFC_MAX) col[(r + 1)*CRW] = jb[0] - mu*t;
-          }
+      }
+      real cd[6], jb[3], jt[3];
+      for (int k = 0; k < 6; k++) cd[k] = S[off::CDOF + 6*j + k];
+      for (int d = 0; d < 3; d++) {
+        const real* dir = f + 3*d;
+        real w1[3], w2[3];
+        cross3(w1, off1, dir);
+        cross3(w2, off2, dir);
+        const real dl = dot3(dir, cd + 3);
+        const real v2 = dl + dot3(w2, cd), v1 = dl + dot3(w1, cd);
+        jb[d] = (in2 ? v2 : R(0)) - (in1 ? v1 : R(0));
+        const real vr = dot3(dir, cd);
+        jt[d] = (in2 ? vr : R(0)) - (in1 ? vr : R(0));
+      }
+      real* col = S + off::ROWS + j;
+      if (dim == 1) {
+        if (r0 < NEFC_MAX) col[r0*CRW] = jb[0];
+      } else {
+        for (int k = 1; k < dim; k++) {
+          const real mu = R(pair_friction[5*p + k - 1]);
+          const real t = k < 3 ? jb[k] : jt[k - 3];
+          const int r = r0 + 2*(k - 1);
+          if (r < NEFC_MAX) col[r*CRW] = jb[0] + mu*t;
+          if (r + 1 < NEFC_MAX) col[(r + 1)*CRW] = jb[0] - mu*t;
         }
       }
-      nefc = r0 + nrow < NEFC_MAX ? r0 + nrow : NEFC_MAX;
     }
+    nefc = rows_after < NEFC_MAX ? rows_after : NEFC_MAX;
     warn = gor_bits(warn);
     gsync();
   }
@@ -1009,6 +1170,7 @@ struct Coop {
 
   // ---- Newton solver (same algorithm and stopping rules as solve_newton in
   // dmc_kernels.hip; sums over dofs and rows are group reductions) -----------
+  static constexpr int ROUNDS = (NEFC_MAX + G - 1)/G;   // lane rounds needed to cover the rows
   struct Ls { real alpha, dcost, d0, d1; };
   __device__ void ls_eval(Ls& P, real alpha, real q1, real q2) const {
     real dcost = 0, d0 = 0, d1 = 0;
@@ -1043,12 +1205,24 @@ struct Coop {
     rows_load(H, off::MM);
     for (;; iter++) {
       // constraint forces of the active rows (lane = row); the first iteration
-      // adds every active row to H
-      for (int r = l; r < nefc; r += G) {
-        real* row = S + off::ROWS + r*CRW;
-        const real jar = row[CR_JAR];
-        row[CR_F] = jar < 0 ? -row[CR_D]*jar : R(0);
-        if (iter == 0) row[CR_FLIP] = jar < 0 ? R(1) : R(0);
+      // adds every active row to H.  The rows the dof lanes have to visit --
+      // active ones for the force, flipped ones also for H -- are collected as
+      // bit masks, so that pass touches no inactive row.
+      unsigned long long visit[ROUNDS], flipped[ROUNDS];
+      _Pragma("unroll")
+      for (int t = 0; t < ROUNDS; t++) {
+        const int r = l + t*G;
+        bool act = false, flp = false;
+        if (r < nefc) {
+          real* row = S + off::ROWS + r*CRW;
+          const real jar = row[CR_JAR];
+          act = jar < 0;
+          row[CR_F] = act ? -row[CR_D]*jar : R(0);
+          if (iter == 0) row[CR_FLIP] = act ? R(1) : R(0);
+          flp = iter == 0 ? act : row[CR_FLIP] != 0;
+        }
+        flipped[t] = gballot(flp);
+        visit[t] = gballot(act) | flipped[t];
       }
       gsync();
       // lane = dof: qfrc_constraint, gradient, changes of row i of H
@@ -1058,30 +1232,34 @@ struct Coop {
         real fc[RNV];
         _Pragma("unroll")
         for (int t = 0; t < RNV; t++) fc[t] = 0;
-        for (int r = 0; r < nefc; r++) {
-          const real* row = S + off::ROWS + r*CRW;
-          const real flip = row[CR_FLIP];
-          if (!(row[CR_JAR] < 0) && flip == 0) continue;
-          const real f = row[CR_F];
-          if (flip != 0) {
-            const real D = flip*row[CR_D];
-            real jr[NVX];
-            _Pragma("unroll")
-            for (int k = 0; k < NV; k++) jr[k] = row[k];
-            _Pragma("unroll")
-            for (int t = 0; t < RNV; t++) {
-              const int i = l + t*G;
-              const real ji = i < NV ? row[i] : R(0);
-              fc[t] += ji*f;
-              const real s = D*ji;
+        _Pragma("unroll")
+        for (int tr = 0; tr < ROUNDS; tr++) {
+          unsigned long long m = visit[tr];
+          while (m) {
+            const int b = first_bit(m);
+            m &= m - 1;
+            const real* row = S + off::ROWS + (b + tr*G)*CRW;
+            const real f = row[CR_F];
+            if ((flipped[tr] >> b) & 1) {
+              const real D = row[CR_FLIP]*row[CR_D];
+              real jr[NVX];
               _Pragma("unroll")
-              for (int k = 0; k < NV; k++) H.a[t][k] += s*jr[k];
-            }
-          } else {
-            _Pragma("unroll")
-            for (int t = 0; t < RNV; t++) {
-              const int i = l + t*G;
-              fc[t] += (i < NV ? row[i] : R(0))*f;
+              for (int k = 0; k < NV; k++) jr[k] = row[k];
+              _Pragma("unroll")
+              for (int t = 0; t < RNV; t++) {
+                const int i = l + t*G;
+                const real ji = i < NV ? row[i] : R(0);
+                fc[t] += ji*f;
+                const real s = D*ji;
+                _Pragma("unroll")
+                for (int k = 0; k < NV; k++) H.a[t][k] += s*jr[k];
+              }
+            } else {
+              _Pragma("unroll")
+              for (int t = 0; t < RNV; t++) {
+                const int i = l + t*G;
+                fc[t] += (i < NV ? row[i] : R(0))*f;
+              }
             }
           }
         }
@@ -1234,6 +1412,40 @@ struct Coop {
     gsync();
   }
 
+  // limits, collision detection, contact Jacobians, reference accelerations
+  __device__ void constraint_rows() {
+    ncon = 0; nefc = 0;
+    limit_rows();
+    PROF(PH_LIMIT);
+    if (NPAIR > 0) contact_rows();
+    PROF(PH_CROWS);
+    finish_rows();
+    PROF(PH_FINISH);
+  }
+  // wave 1's share of one forward() (DUO): the barriers pair with forward()'s
+  __device__ void forward_rows() {
+    l = opaque(l);
+    wsync();
+    com_vel();        // ends with a phase boundary: the results are in LDS
+    epoch++;
+    if (l == 0) flag_write(off::XCH + 3, epoch);
+    warn = 0;
+    constraint_rows();
+    if (l == 0) { S[off::XCH] = (real)nefc; S[off::XCH + 1] = (real)ncon; S[off::XCH + 2] = (real)(int)warn; }
+    wsync();
+  }
+  // wave 1's share of one physics_step() (DUO)
+  __device__ void step_rows() {
+    forward_rows();
+    if (EULER_OFFLOAD) {
+      Rows A;
+      damped_factor(A, off::GEOM);
+      wsync();        // qfrc_smooth + qfrc_constraint are final, wave 0 is done with the scratch
+      damped_solve(A);
+      wsync();
+    }
+  }
+
   // forward dynamics at (qpos, qvel, ctrl): qacc, qfrc_smooth, qfrc_constraint
   __device__ void forward(bool actuation, real tol) {
     PROF(PH_EULER);
@@ -1241,18 +1453,33 @@ struct Coop {
     PROF(PH_KIN);
     com_pos();
     PROF(PH_COM);
+    wsync();          // frames, cdof and subtree coms are final: wave 1 starts on the rows
     crb_matrix();
-    com_vel();
-    PROF(PH_VEL);
-    smooth_forces(actuation);
-    PROF(PH_SMOOTH);
-    ncon = 0; nefc = 0; iters = 0;
-    limit_rows();
-    PROF(PH_LIMIT);
-    if (NPAIR > 0) contact_rows();
-    PROF(PH_CROWS);
-    finish_rows();
-    PROF(PH_FINISH);
+    Rows L;
+    if (!DUO) {
+      com_vel();
+      PROF(PH_VEL);
+      smooth_forces(actuation);
+      factor_mass(L);
+    } else {
+      // wave 1 does the velocity stage first and flags it; by the time M is
+      // factorised here the flag is up
+      factor_mass(L);
+      epoch++;
+      while (flag_read(off::XCH + 3) != epoch) flag_pause();
+      PROF(PH_VEL);
+      smooth_forces(actuation);
+    }
+    smooth_acc(L);
+    iters = 0;
+    if (!DUO) {
+      constraint_rows();
+    } else {
+      wsync();        // rows, contacts and their counts are in LDS
+      nefc = (int)S[off::XCH]; ncon = (int)S[off::XCH + 1];
+      warn |= (unsigned)(int)S[off::XCH + 2];
+      PROF(PH_FINISH);
+    }
     if (nefc == 0) {
       for (int i = l; i < NV; i += G) { S[off::QACC + i] = S[off::QAS + i]; S[off::FC + i] = 0; }
       gsync();
@@ -1341,10 +1568,42 @@ struct Coop {
     return gany(ba);
   }
 
+  // Euler's implicit joint damping: Cholesky factor of M + h D, and
+  // GRAD <- (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
+  static constexpr bool damped() { return coop_damped(); }
+  __device__ void damped_factor(Rows& A, int panel) {
+    const real h = R(timestep);
+    rows_load(A, off::MM);
+    _Pragma("unroll")
+    for (int t = 0; t < RNV; t++) {
+      const int i = l + t*G;
+      _Pragma("unroll")
+      for (int k = 0; k < NV; k++)
+        if (i == k) A.a[t][k] += h*R(dof_damping[k]);
+    }
+    rows_chol(A, panel);
+  }
+  __device__ void damped_solve(const Rows& A) {
+    real rhs[RNV];
+    _Pragma("unroll")
+    for (int t = 0; t < RNV; t++) {
+      const int i = l + t*G;
+      rhs[t] = i < NV ? S[off::FS + i] + S[off::FC + i] : R(0);
+    }
+    rows_solve(A, off::HH, rhs);
+    _Pragma("unroll")
+    for (int t = 0; t < RNV; t++) if (l + t*G < NV) S[off::GRAD + l + t*G] = rhs[t];
+    gsync();
+  }
+
   // one `Physics.step()`; `stale`: acceleration from the position/velocity
   // stage of the reset state, applied to the current state (the first of the
   // cheetah's settle steps, see physics_step in dmc_kernels.hip)
   __device__ void physics_step(real tol, bool stale = false) {
+    // nothing derived from the lane index is carried across steps: left alone,
+    // the compiler precomputes a few dozen per-lane LDS addresses before the
+    // substep loop and then spills them
+    l = opaque(l);
     const real h = R(timestep);
     check_state();
     if (!RK4) {
@@ -1371,28 +1630,18 @@ struct Coop {
         for (int t = 0; t < KV; t++) if (l + t*G < NV) S[off::QVEL + l + t*G] = vkeep[t];
         gsync();
       }
+      if (EULER_OFFLOAD) {   // wave 1 solves (M + h D) a = f with the factor it made meanwhile
+        wsync();
+        wsync();
+      }
       if (bad_qacc()) { warn |= WARN_BADQACC; reset_state(); return; }
-      bool damped = false;
-      for (int i = 0; i < NV; i++) damped |= dof_damping[i] > 0;
       int src = off::QACC;
-      if (damped) {   // implicit in the joint damping: (M + h D) a = f
-        Rows A;
-        rows_load(A, off::MM);
-        real rhs[RNV];
-        _Pragma("unroll")
-        for (int t = 0; t < RNV; t++) {
-          const int i = l + t*G;
-          rhs[t] = 0;
-          _Pragma("unroll")
-          for (int k = 0; k < NV; k++)
-            if (i == k) A.a[t][k] += h*R(dof_damping[k]);
-          if (i < NV) rhs[t] = S[off::FS + i] + S[off::FC + i];
+      if (damped()) {   // implicit in the joint damping: (M + h D) a = f
+        if (!EULER_OFFLOAD) {
+          Rows A;
+          damped_factor(A, off::HH);
+          damped_solve(A);
         }
-        rows_chol(A, off::HH);
-        rows_solve(A, off::HH, rhs);
-        _Pragma("unroll")
-        for (int t = 0; t < RNV; t++) if (l + t*G < NV) S[off::GRAD + l + t*G] = rhs[t];
-        gsync();
         src = off::GRAD;
       }
       for (int i = l; i < NV; i += G) S[off::QVEL + i] += h*S[src + i];
@@ -1454,8 +1703,10 @@ struct Coop {
     for (int i = l; i < NV; i += G) {
       S[off::QVEL + i] = a.qvel[sidx(i, e, n, NVX)]; S[off::WARM + i] = a.warm[sidx(i, e, n, NVX)];
     }
+    for (int k = l; k < NV*NVP; k += G) S[off::MM + k] = 0;   // structural zeros stay
+    if (l == 0) flag_write(off::XCH + 3, 0);
     time = a.time[e];
-    warn = 0; ncon = 0; nefc = 0; iters = 0;
+    warn = 0; ncon = 0; nefc = 0; iters = 0; epoch = 0;
     if (l < (NTOUCH > 0 ? NTOUCH : 1)) S[off::TOUCH + l] = 0;
     for (int i = l; i < NTASKDATA; i += G) S[off::TASKD + i] = a.taskdata[sidx(i, e, n, NTDX)];
   }
@@ -1503,19 +1754,54 @@ struct Coop {
 
 __shared__ __attribute__((aligned(16))) real coop_lds[ENV_WORDS*EPB];
 
+// Workgroups are handed to the 8 XCDs round-robin (workgroup b runs on XCD
+// b % 8) and every XCD has its own L2.  With env = workgroup, the 100-byte
+// state rows and the 4-byte scalars of neighbouring envs -- which share
+// cache lines -- would be read and written through eight different L2s, each
+// moving the whole line.  This permutation gives every XCD one contiguous range
+// of envs instead (a bijection for any number of workgroups).
+DEV int xcd_contiguous(int b, int nb) {
+  const int q = nb/8, r = nb % 8, x = b % 8;
+  return x*q + (x < r ? x : r) + b/8;
+}
+
 // nsub x Physics.step, then observation + reward of the new state
-extern "C" __global__ void __launch_bounds__(64)
+// DUO: two waves of every env, four envs per CU by LDS => two waves per SIMD,
+// so a wave may use half of the SIMD's 512 registers
+#if DMC_COOP_DUO && DMC_GROUP == 64
+#define DMC_COOP_OCCUPANCY __attribute__((amdgpu_waves_per_eu(2)))
+#else
+#define DMC_COOP_OCCUPANCY
+#endif
+extern "C" __global__ void __launch_bounds__(NTHREADS) DMC_COOP_OCCUPANCY
 dmc_step(DmcArgs a) {
+#ifdef DMC_COOP_PROFILE
+  const long long tstart_ = wall_clock64();
+#endif
   stage_tables();
-  const int slot = threadIdx.x/G;
-  const int e = blockIdx.x*EPB + slot;
-  if (e >= a.nenv) return;               // whole groups leave together
+  const int slot = DUO ? 0 : threadIdx.x/G;
+  const int e = xcd_contiguous(blockIdx.x, (a.nenv + EPB - 1)/EPB)*EPB + slot;
+  if (e >= a.nenv) return;               // whole groups (DUO: both waves) leave together
   Coop C;
   C.S = coop_lds + slot*ENV_WORDS;
   C.l = threadIdx.x % G;
   const int l = C.l;
   real* S = C.S;
   const long long n = a.nenv;
+#ifdef DMC_COOP_PROFILE
+  for (int k = 0; k < PH_N; k++) C.tprof[k] = 0;
+  C.tlast = wall_clock64();
+#endif
+#if !defined(DMC_HOST_SHIM) && !defined(DMC_COOP_NO_PRIO)
+  // the two waves of an env (or of neighbouring envs) share a SIMD: the wave
+  // on the critical path issues first, the row builder fills the gaps
+  if (DUO) { if (threadIdx.x < 64) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+#endif
+  if (DUO && threadIdx.x >= 64) {        // the row-building wave: one forward() per step
+    C.ncon = 0; C.nefc = 0; C.warn = 0; C.iters = 0; C.time = 0; C.epoch = 0;
+    for (int s = 0; s < a.nsub; s++) C.step_rows();
+    return;
+  }
   C.load(a, e);
   if (a.flags & 1) {
     bool bc = false;
@@ -1534,10 +1820,6 @@ dmc_step(DmcArgs a) {
   }
   gsync();
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
-#ifdef DMC_COOP_PROFILE
-  for (int k = 0; k < PH_N; k++) C.tprof[k] = 0;
-  C.tlast = wall_clock64();
-#endif
   for (int s = 0; s < a.nsub; s++)
     C.physics_step(tol, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
 #ifdef DMC_COOP_PROFILE
@@ -1551,16 +1833,22 @@ dmc_step(DmcArgs a) {
 #ifdef DMC_COOP_PROFILE
   { const long long t_ = wall_clock64(); C.tprof[PH_OBS] += t_ - C.tlast; }
   if (l == 0) for (int k = 0; k < PH_N && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = (real)C.tprof[k];
+  if (l == 0 && PH_N + 4 <= NOBS) {   // wave placement and life time: start, end (10 ns ticks, 20 bits), HW_ID, XCC_ID
+    real* o = a.obs + (long long)e*a.obs_se + PH_N;
+    o[0] = (real)(int)(tstart_ & 0xFFFFF); o[1] = (real)(int)(wall_clock64() & 0xFFFFF);
+    o[2] = (real)(int)(__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFFFF);
+    o[3] = (real)(int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xF);
+  }
 #endif
   C.store(a, e);
 }
 
 // observation / reward / sensors of the current state (reset, after_reset)
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(NTHREADS) DMC_COOP_OCCUPANCY
 dmc_observe(DmcArgs a) {
   stage_tables();
-  const int slot = threadIdx.x/G;
-  const int e = blockIdx.x*EPB + slot;
+  const int slot = DUO ? 0 : threadIdx.x/G;
+  const int e = xcd_contiguous(blockIdx.x, (a.nenv + EPB - 1)/EPB)*EPB + slot;
   if (e >= a.nenv) return;
   Coop C;
   C.S = coop_lds + slot*ENV_WORDS;
@@ -1568,6 +1856,15 @@ dmc_observe(DmcArgs a) {
   const int l = C.l;
   real* S = C.S;
   const long long n = a.nenv;
+#ifdef DMC_COOP_PROFILE
+  for (int k = 0; k < PH_N; k++) C.tprof[k] = 0;
+  C.tlast = 0;
+#endif
+  if (DUO && threadIdx.x >= 64) {
+    C.ncon = 0; C.nefc = 0; C.warn = 0; C.iters = 0; C.time = 0; C.epoch = 0;
+    if (NTOUCH > 0) C.forward_rows();
+    return;
+  }
   C.load(a, e);
   for (int i = l; i < NU; i += G) S[off::CTRL + i] = a.ctrl_store[sidx(i, e, n, NUX)];
   gsync();
@@ -1595,5 +1892,5 @@ extern "C" __device__ const int dmc_info[20] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     1 /*workspace reals per env: none, everything is in LDS*/, TASK, NCON_MAX, NEFC_MAX,
     INTEGRATOR, NPAIR, EPB /*envs per 64-lane workgroup*/,
-    DMC_ENV_MAJOR /*state fields are [env][k]*/, NTASKDATA, 64 /*threads per workgroup*/,
+    DMC_ENV_MAJOR /*state fields are [env][k]*/, NTASKDATA, NTHREADS /*threads per workgroup*/,
     0, 0};

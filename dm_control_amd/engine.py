@@ -366,9 +366,12 @@ class Physics(_control.Physics):
   # When the mode is "auto", batches up to `max_batch` use the several-lanes-
   # per-env kernel (build mode "coop") with `group` lanes per env: one env per
   # lane needs >= 64 envs per CU to fill the chip, one env per wavefront fills
-  # it at 4 per CU, two envs per wavefront at 8.  ((max_batch, group), ...) in
-  # increasing max_batch; measured cross-overs per domain.
+  # it at 4 per CU, two envs per wavefront at 8; 128 = one env per wavefront
+  # plus a helper wavefront, fastest while the batch runs in one round.
+  # ((max_batch, group), ...) in increasing max_batch; measured cross-overs per
+  # domain (profiles/r02_kernel_shape_sweep.txt).
   _COOP_POLICY = ()
+  _GROUP = 64                 # lanes per env of build mode "coop" (128: two wavefronts)
 
   def __init__(self, model, batch_size=None, device=0, precision='f32',
                task=None, ncon_max=None, build_mode=None, group=None):
@@ -387,10 +390,14 @@ class Physics(_control.Physics):
     self._profile_seconds = 0.0
     self._profile_calls = 0
     self._build_mode = build_mode or self._BUILD_MODE
-    self._group = group or 64
+    self._group = group or self._GROUP
+    if group is None and precision == 'f64' and self._group == 128:
+      self._group = 64          # fp64 rows need the registers of a whole SIMD lane slot
     if build_mode is None and self._build_mode == 'auto' and precision != 'mixed':
       for max_batch, lanes in self._COOP_POLICY:
         if self._batch_size <= max_batch:
+          if lanes == 128 and precision == 'f64':
+            lanes = 64
           self._build_mode, self._group = 'coop', lanes
           break
     path = build.build_model(
@@ -438,6 +445,9 @@ class Physics(_control.Physics):
   @property
   def kernel_shape(self):
     info = self._hip_model.info
+    if info.lanes_per_env > 64:
+      return ('64 lanes per env + a second wavefront building the constraint '
+              'rows (csrc/dmc_coop.hip)')
     if info.lanes_per_env > 1:
       return '%d lanes per env (csrc/dmc_coop.hip)' % info.lanes_per_env
     return 'one env per lane (csrc/dmc_kernels.hip)'

@@ -43,12 +43,12 @@ int main(int argc, char** argv) {
   a.reward = rew.data(); a.episode_return = ret.data(); a.sensordata = sens.data();
   a.xpos = xpos.data(); a.xmat = xmat.data(); a.qacc = qacc.data();
   a.warn = warn.data(); a.stats = stats.data(); a.ws = ws.data();
-  for (int t = 0; t < EPB; t++) pthread_barrier_init(&shim_teams[t].bar, nullptr, G);
-  pthread_barrier_init(&shim_block_barrier, nullptr, 64);
+  for (int t = 0; t < NTHREADS/G; t++) pthread_barrier_init(&shim_teams[t].bar, nullptr, G);
+  pthread_barrier_init(&shim_block_barrier, nullptr, NTHREADS);
   for (int t = 0; t < steps; t++) {
-    pthread_t th[64];
-    for (size_t i = 0; i < 64; i++) pthread_create(&th[i], nullptr, lane_main, (void*)i);
-    for (int i = 0; i < 64; i++) pthread_join(th[i], nullptr);
+    pthread_t th[NTHREADS];
+    for (size_t i = 0; i < NTHREADS; i++) pthread_create(&th[i], nullptr, lane_main, (void*)i);
+    for (int i = 0; i < NTHREADS; i++) pthread_join(th[i], nullptr);
     for (int e = 0; e < n; e++) {
       printf("STEP %d %d", t, e);
       for (int i = 0; i < NQ; i++) printf(" %.17g", (double)qpos[e*nq + i]);

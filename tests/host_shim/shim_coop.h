@@ -6,6 +6,7 @@
 // TEST INFRASTRUCTURE ONLY -- nothing in dm_control_amd/ can reach it.
 #pragma once
 #include <pthread.h>
+#include <sched.h>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -30,8 +31,8 @@ struct ShimTeam {
   pthread_barrier_t bar;
   alignas(8) unsigned char buf[DMC_GROUP][8];
 };
-static ShimTeam shim_teams[64/DMC_GROUP];
-static pthread_barrier_t shim_block_barrier;   // all 64 lanes
+static ShimTeam shim_teams[128/DMC_GROUP];   // 64 lanes, or two wavefronts of one env
+static pthread_barrier_t shim_block_barrier;   // all lanes of the workgroup
 static inline void __syncthreads() { pthread_barrier_wait(&shim_block_barrier); }
 static inline ShimTeam& shim_team() { return shim_teams[threadIdx.x/DMC_GROUP]; }
 static inline int shim_lane() { return (int)(threadIdx.x % DMC_GROUP); }

@@ -40,10 +40,12 @@ W = wrapper
 # about 10x the values observed on MI355X (round 2, both kernels; observed
 # medians: cartpole 3.6e-8, cheetah 1.2e-7, humanoid 9.6e-7, walker 6.6e-7,
 # pendulum 3.5e-8, acrobot 4.3e-8, hopper 2.9e-7, reacher 1.1e-7, point_mass
-# 8.7e-9; observed maxima 1.1e-7 ... 1.2e-4)
+# 8.7e-9; observed maxima 1.1e-7 ... 1.2e-4, and 1.8e-3 for one humanoid sample
+# of the two-envs-per-wave build: the maximum is set by single steps in which
+# a constraint row sits within rounding of its activation threshold)
 FP32_PER_STEP = {
     'cartpole': (4e-7, 1e-6, 2e-6), 'cheetah': (1.5e-6, 3e-5, 2e-4),
-    'humanoid': (1e-5, 1.5e-4, 1.5e-3), 'walker': (8e-6, 8e-5, 5e-4),
+    'humanoid': (1e-5, 1.5e-4, 5e-3), 'walker': (8e-6, 8e-5, 5e-4),
     'pendulum': (4e-7, 1.2e-6, 2e-6), 'acrobot': (5e-7, 1.2e-6, 3e-6),
     'hopper': (3e-6, 5e-5, 3e-4), 'reacher': (1.2e-6, 1.2e-5, 3e-5),
     'point_mass': (1e-7, 2.5e-6, 2e-5)}
@@ -141,14 +143,17 @@ def test_fp32_build_matches_oracle_per_step(name, nsub):
 @pytest.mark.parametrize('name,nsub,group', [
     ('cartpole', 1, 64), ('cheetah', 1, 64), ('walker', 10, 64),
     ('hopper', 4, 64), ('point_mass', 1, 64), ('cheetah', 1, 32),
-    ('humanoid', 5, 32)])
+    ('humanoid', 5, 32), ('humanoid', 5, 64), ('humanoid', 5, 128),
+    ('cheetah', 1, 128), ('walker', 10, 128), ('hopper', 4, 128)])
 def test_several_lanes_per_env_build_matches_oracle(name, nsub, group):
   """csrc/dmc_coop.hip (mode='coop': a group of lanes per env, working set in
-  LDS) on models whose default is the one-lane kernel, and with two envs per
-  wave; the humanoid's default build (group 64) is covered by the per-step
-  tests above.  Odd batch: the last workgroup is partially filled."""
-  if group == 64:
-    e = _teacher_forced(name, 'f64', nenv=33, steps=10, nsub=nsub, mode='coop')
+  LDS) on models whose default is the one-lane kernel, with two envs per wave
+  (group 32), and with the second wavefront that builds the constraint rows
+  and factorises M + h D meanwhile (group 128, the humanoid's fp32 default).
+  Odd batch: the last workgroup is partially filled."""
+  if group >= 64:
+    e = _teacher_forced(name, 'f64', nenv=33, steps=10, nsub=nsub, mode='coop',
+                        group=group)
     assert e.max() <= 1e-9, e.max()
   e = _teacher_forced(name, 'f32', nenv=65, steps=10, nsub=nsub, mode='coop',
                       group=group)
@@ -1079,7 +1084,9 @@ def test_free_run_trajectories_several_lanes_kernel(name, nsub, steps):
   assert contacts > steps*nenv//4           # the floor was involved
   ref = np.array([d.qpos.copy() for d in datas])
   for precision in ('f64', 'f32'):
-    hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv, 'coop')
+    # group 128: one env per 64 lanes plus the row-building wavefront
+    hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv, 'coop',
+                           group=128)
     hb.set_state(qpos.T, qvel.T)
     for t in range(steps):
       hb.step_host(ctrls[t], nsub)

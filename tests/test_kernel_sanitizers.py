@@ -105,7 +105,8 @@ def _build_coop(model, task, tmp_path, sanitizer, group):
   exe = tmp_path/'harness_coop'
   cmd = ['g++', '-std=c++17', '-O1', '-g', '-pthread',
          '-fsanitize=' + sanitizer, '-fno-omit-frame-pointer',
-         '-DDMC_REAL_IS_DOUBLE', '-DDMC_GROUP=%d' % group,
+         '-DDMC_REAL_IS_DOUBLE', '-DDMC_GROUP=%d' % min(group, 64),
+         '-DDMC_COOP_DUO=%d' % (group == 128),
          '-DDMC_MODEL_HEADER="%s"' % header,
          '-DDMC_KERNEL_SOURCE="%s"' % COOP_KERNEL,
          '-I', os.path.join(ROOT, 'dm_control_amd', 'csrc'), '-I', SHIM,
@@ -122,13 +123,18 @@ def _build_coop(model, task, tmp_path, sanitizer, group):
     ('cheetah', 'thread', 32, 12),
     ('primitives', 'thread', 32, 20),
     ('cartpole', 'address,undefined', 64, 6),
-    ('hopper', 'address,undefined', 64, 12)])
+    ('hopper', 'address,undefined', 64, 12),
+    # two wavefronts per env: the row-building wave runs concurrently with the
+    # mass-matrix / velocity wave, ThreadSanitizer watches their LDS regions
+    ('humanoid', 'thread', 128, 9),
+    ('hopper', 'thread', 128, 10),
+    ('humanoid', 'address,undefined', 128, 9)])
 def test_several_lanes_per_env_source(name, sanitizer, group, steps, tmp_path):
   """csrc/dmc_coop.hip with one thread per lane (tests/host_shim/shim_coop.h):
   a phase hand-over is a pthread barrier, so ThreadSanitizer reports any LDS
   word that crosses lanes without one, AddressSanitizer every index; the
   trajectories of all envs of the workgroup are compared with the oracle."""
-  nenv = 64//group
+  nenv = max(1, 64//group)      # group 128: one env, two wavefronts
   if name == 'primitives':
     model, task = compiler.from_xml_string(kat_models.PRIMITIVES), 0
     q = np.tile(model.qpos0, (nenv, 1))

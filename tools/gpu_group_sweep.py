@@ -1,4 +1,9 @@
-"""Scratch: group size sweep of the several-lanes-per-env kernel."""
+"""Kernel-only sweep over the step kernels of one model: one env per lane, one
+env per 64 lanes with and without the second (row-building) wavefront, one env
+per 32 lanes.  Data behind `Physics._COOP_POLICY`.
+
+  python tools/gpu_group_sweep.py walker [batch sizes]
+"""
 import os
 import sys
 import numpy as np
@@ -7,15 +12,23 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import helpers
 from dm_control_amd import build, wrapper as W
 name = sys.argv[1]
+batches = [int(x) for x in sys.argv[2:]] or [256, 1024, 2048, 4096, 8192]
 model = helpers.load_model(name)
 nsub = {'cheetah': 1, 'walker': 10, 'hopper': 4, 'humanoid': 5}[name]
-for B in (1024, 4096, 8192, 16384):
+VARIANTS = (('one env per lane', 'auto', 64, ()),
+            ('64 lanes x 2 waves', 'coop', 64, ()),
+            ('64 lanes', 'coop', 64, ('-DDMC_COOP_DUO=0',)),
+            ('32 lanes', 'coop', 32, ()))
+for B in batches:
   line = '%s B=%d:' % (name, B)
-  for mode, group in (('auto', 0), ('coop', 64), ('coop', 32), ('coop', 16)):
+  for label, mode, group, flags in VARIANTS:
+    if name == 'humanoid' and mode == 'auto' and B > 1024:
+      continue
     try:
-      path = build.build_model(model, helpers.TASKS[name], 'f32', mode=mode, group=group or 64)
+      path = build.build_model(model, helpers.TASKS[name], 'f32', mode=mode, group=group,
+                               extra_flags=flags)
     except Exception as e:   # LDS does not fit
-      line += '  %s/%d n/a' % (mode, group); continue
+      line += '  %s n/a' % label; continue
     hm = W.HipModel(path); hb = W.HipBatch(hm, B)
     qpos, qvel = helpers.initial_states(model, name, B, seed=1)
     hb.set_state(qpos.T, qvel.T)
@@ -25,6 +38,6 @@ for B in (1024, 4096, 8192, 16384):
     hb.sync(); hb.timer_start()
     for t in range(60): hb.step_host(None, nsub)
     ms, n = hb.timer_stop()
-    line += '  %s/%d %.4f ms %.1f M/s' % (mode, group, ms/n, B/(ms/n)/1e3)
+    line += '  | %s %.4f ms %.2f M/s' % (label, ms/n, B/(ms/n)/1e3)
     hb.free(); hm.free()
   print(line, flush=True)
