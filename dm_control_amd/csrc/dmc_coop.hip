@@ -368,23 +368,23 @@ struct Coop {
   // one-way signal between the two wavefronts of an env (DUO): an LDS word
   // written with release and polled with acquire semantics
 #ifndef DMC_HOST_SHIM
-  __device__ void flag_write(int word, int value) {
+  __device__ __forceinline__ void flag_write(int word, int value) {
     __hip_atomic_store(reinterpret_cast<int*>(S + word), value, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  __device__ int flag_read(int word) const {
+  __device__ __forceinline__ int flag_read(int word) const {
     return __hip_atomic_load(reinterpret_cast<const int*>(S + word), __ATOMIC_ACQUIRE,
                              __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 #else
-  __device__ void flag_write(int word, int value) {
+  __device__ __forceinline__ void flag_write(int word, int value) {
     __atomic_store_n(reinterpret_cast<int*>(S + word), value, __ATOMIC_RELEASE);
   }
-  __device__ int flag_read(int word) const {
+  __device__ __forceinline__ int flag_read(int word) const {
     return __atomic_load_n(reinterpret_cast<const int*>(S + word), __ATOMIC_ACQUIRE);
   }
 #endif
-  __device__ static void flag_pause() {
+  __device__ __forceinline__ static void flag_pause() {
 #ifndef DMC_HOST_SHIM
     __builtin_amdgcn_s_sleep(2);
 #else
@@ -402,7 +402,7 @@ struct Coop {
   // round trip.)
   struct Rows { real a[RNV][NVX]; };
 
-  __device__ void rows_load(Rows& A, int src) const {
+  __device__ __forceinline__ void rows_load(Rows& A, int src) const {
     _Pragma("unroll")
     for (int t = 0; t < RNV; t++) {
       const int i = l + t*G;
@@ -419,28 +419,48 @@ struct Coop {
   // (column, column) pair.  The panel buffer is the solve scratch at `panel`
   // (two halves used alternately, so one phase boundary per block suffices).
   static constexpr int CB = DMC_COOP_CB;
-  __device__ int rows_chol(Rows& A, int panel) {
+  __device__ __forceinline__ int rows_chol(Rows& A, int panel) {
     int nbad = 0;
     _Pragma("unroll")
     for (int jb = 0; jb < NV; jb += CB) {
       const int w = NV - jb < CB ? NV - jb : CB;
       real pl[RNV][CB];
+      // The diagonal block travels to every lane first (independent register
+      // broadcasts) and every lane factorises it for itself, repeating the
+      // pivot lanes' arithmetic bit for bit: the columns of the block then
+      // need no cross-lane traffic inside their dependent chain.
+      real Dg[CB][CB], invd[CB];
+      _Pragma("unroll")
+      for (int a = 0; a < w; a++) {
+        _Pragma("unroll")
+        for (int b = 0; b <= a; b++)
+          Dg[a][b] = gbcast(A.a[(jb + a)/G][jb + b], (jb + a) % G);
+      }
+      _Pragma("unroll")
+      for (int jj = 0; jj < w; jj++) {
+        real d = Dg[jj][jj];
+        if (!(d >= DMC_MINVAL)) { d = DMC_MINVAL; nbad++; }
+        invd[jj] = rsqrt_(d);
+        _Pragma("unroll")
+        for (int a = jj + 1; a < w; a++) Dg[a][jj] *= invd[jj];
+        _Pragma("unroll")
+        for (int a = jj + 1; a < w; a++) {
+          _Pragma("unroll")
+          for (int b = jj + 1; b <= a; b++) Dg[a][b] -= Dg[a][jj]*Dg[b][jj];
+        }
+      }
       _Pragma("unroll")
       for (int jj = 0; jj < w; jj++) {
         const int j = jb + jj;
-        real d = gbcast(A.a[j/G][j], j % G);
-        if (!(d >= DMC_MINVAL)) { d = DMC_MINVAL; nbad++; }
-        const real inv = rsqrt_(d);
         _Pragma("unroll")
         for (int t = 0; t < RNV; t++) {
-          pl[t][jj] = A.a[t][j]*inv;
-          A.a[t][j] = (l + t*G == j) ? inv : pl[t][jj];
+          pl[t][jj] = A.a[t][j]*invd[jj];
+          A.a[t][j] = (l + t*G == j) ? invd[jj] : pl[t][jj];
         }
         _Pragma("unroll")
-        for (int k = j + 1; k < jb + w; k++) {
-          const real lkj = gbcast(pl[k/G][jj], k % G);
+        for (int k = jj + 1; k < w; k++) {
           _Pragma("unroll")
-          for (int t = 0; t < RNV; t++) A.a[t][k] -= pl[t][jj]*lkj;
+          for (int t = 0; t < RNV; t++) A.a[t][jb + k] -= pl[t][jj]*Dg[k][jj];
         }
       }
       if (jb + w < NV) {
@@ -472,7 +492,7 @@ struct Coop {
   // x = (L L^T)^-1 b, b/x held one entry per lane row.  The backward sweep
   // needs column i of L in lane i: the factor is transposed through the LDS
   // square at `scratch` (one write + one read per entry, all independent).
-  __device__ void rows_solve(const Rows& A, int scratch, real* b) {
+  __device__ __forceinline__ void rows_solve(const Rows& A, int scratch, real* b) {
     _Pragma("unroll")
     for (int t = 0; t < RNV; t++) {
       const int i = l + t*G;
@@ -510,7 +530,7 @@ struct Coop {
     gsync();   // `scratch` may be rewritten by the caller from here on
   }
   // y_i = sum_k M_ik x_k for this lane's rows (M stored full and symmetric)
-  __device__ real mrow_dot(int i, int x) const {
+  __device__ __forceinline__ real mrow_dot(int i, int x) const {
     real s = 0;
     _Pragma("unroll")
     for (int k = 0; k < NV; k++) s += S[off::MM + i*NVP + k]*S[x + k];
@@ -528,7 +548,7 @@ struct Coop {
   //   (4) lane = joint / body: anchors, axes and inertial frames in the world.
   // mj_kinematics composes the same transforms joint by joint in the world
   // frame; the two orders agree to rounding.
-  __device__ void kinematics() {
+  __device__ __forceinline__ void kinematics() {
     for (int j = l; j < NJNT; j += G) {
       const int jt = jnt_type[j], qa = jnt_qposadr[j];
       real q[4] = {1, 0, 0, 0};
@@ -639,7 +659,7 @@ struct Coop {
     gsync();
   }
 
-  __device__ void com_pos() {
+  __device__ __forceinline__ void com_pos() {
     // subtree centre of mass: bodies are depth-first ordered, a subtree is the
     // index range [i, i + body_subtree_n[i]).  lane = (body, axis); the range
     // loop runs its full static length with the terms past the end masked, so
@@ -716,7 +736,7 @@ struct Coop {
   }
 
   // composite inertias and the full symmetric mass matrix
-  __device__ void crb_matrix() {
+  __device__ __forceinline__ void crb_matrix() {
     // composite inertia = range sum of cinert over the subtree, lane = (body, word)
     for (int idx = l; idx < NBODY*10; idx += G) {
       const int i = idx/10, k = idx - 10*i;
@@ -772,7 +792,7 @@ struct Coop {
   //                joint  x  cdof   (mj_comVel: cvel "before the joint");
   //   lane = body: cvel and cacc as sums over the body's dof chain, added in
   //                root-to-leaf order like the reference's walk.
-  __device__ void com_vel() {
+  __device__ __forceinline__ void com_vel() {
     // The chain loops run their full static length with the terms past the end
     // weighted by zero: all index loads, then all data loads, are independent
     // and in flight together instead of one LDS round trip per ancestor.
@@ -826,7 +846,7 @@ struct Coop {
   }
 
   // qfrc_smooth = passive - bias + actuator
-  __device__ void smooth_forces(bool actuation) {
+  __device__ __forceinline__ void smooth_forces(bool actuation) {
     for (int i = l; i < NBODY; i += G) {
       real f[6];
       if (i == 0) { for (int k = 0; k < 6; k++) f[k] = 0; }
@@ -916,12 +936,12 @@ struct Coop {
     PROF(PH_SMOOTH);
   }
   // M = L L^T, and qacc_smooth = M^-1 qfrc_smooth
-  __device__ void factor_mass(Rows& L) {
+  __device__ __forceinline__ void factor_mass(Rows& L) {
     rows_load(L, off::MM);
     if (rows_chol(L, off::HH)) warn |= WARN_INERTIA;
     PROF(PH_FACM);
   }
-  __device__ void smooth_acc(const Rows& L) {
+  __device__ __forceinline__ void smooth_acc(const Rows& L) {
     real b[RNV];
     _Pragma("unroll")
     for (int t = 0; t < RNV; t++) b[t] = l + t*G < NV ? S[off::FS + l + t*G] : R(0);
@@ -932,7 +952,7 @@ struct Coop {
     PROF(PH_SOLVE);
   }
 
-  __device__ void subtree_vel() {
+  __device__ __forceinline__ void subtree_vel() {
     // momentum of every body about the world origin frame, then range sums
     for (int i = l; i < NBODY; i += G) {
       real dif[3], t[3], w[3];
@@ -958,12 +978,12 @@ struct Coop {
   // Rows are created with their metadata parked in the solver slots
   // (CR_D <- R, CR_AREF <- K*imp*(pos - margin), CR_JAR <- B); finish_rows()
   // turns that into D and aref once J is complete.
-  __device__ void row_meta(int r, real pm, real K, real B, real imp, real Rrow) {
+  __device__ __forceinline__ void row_meta(int r, real pm, real K, real B, real imp, real Rrow) {
     real* row = S + off::ROWS + r*CRW;
     row[CR_D] = Rrow; row[CR_AREF] = K*imp*pm; row[CR_JAR] = B;
   }
 
-  __device__ void limit_rows() {
+  __device__ __forceinline__ void limit_rows() {
     if (DISABLEFLAGS & (DSBL_LIMIT | DSBL_CONSTRAINT)) return;
     for (int base = 0; base < NLIMIT; base += G) {
       const int li = base + l;
@@ -999,7 +1019,7 @@ struct Coop {
     }
     warn = (unsigned)gor_bits(warn);
   }
-  __device__ unsigned gor_bits(unsigned w) {
+  __device__ __forceinline__ unsigned gor_bits(unsigned w) {
     int x = (int)w;
 #ifndef DMC_HOST_SHIM
     if (G >= 16) {
@@ -1019,7 +1039,7 @@ struct Coop {
   // narrowphase over the static pair list, strided over the lanes; an ordered
   // prefix sum per stride keeps the contact list in pair order
   // returns the number of constraint rows once the contacts' rows are counted
-  __device__ int detect_contacts() {
+  __device__ __forceinline__ int detect_contacts() {
     if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return nefc;
     for (int g = l; g < NGEOM; g += G) {
       const int b = geom_bodyid[g];
@@ -1040,7 +1060,7 @@ struct Coop {
     int nrow_total = nefc;
     for (int base = 0; base < NPAIR; base += G) {
       const int p = base + l;
-      RawCon rc[4];
+      RawCon rc[4] = {};
       int mask = 0;
       if (p < NPAIR) mask = collide_pair(S + off::GEOM, p, rc);
       const int cnt = __builtin_popcount((unsigned)mask);
@@ -1089,7 +1109,7 @@ struct Coop {
   // simultaneous contacts cost one pass instead of one pass each.  Every lane
   // derives its contact's frame and row parameters itself (the per-pair model
   // tables are indexed per lane); the lane of dof 0 writes the row metadata.
-  __device__ void contact_rows() {
+  __device__ __forceinline__ void contact_rows() {
     const int rows_after = detect_contacts();
     PROF(PH_DETECT);
     for (int idx = l; idx < ncon*NV; idx += G) {
@@ -1155,7 +1175,7 @@ struct Coop {
   }
 
   // D and aref of every row (lane = row): aref = -B (J qvel) - K imp (pos - margin)
-  __device__ void finish_rows() {
+  __device__ __forceinline__ void finish_rows() {
     for (int r = l; r < nefc; r += G) {
       real* row = S + off::ROWS + r*CRW;
       real vel = 0;
@@ -1172,7 +1192,7 @@ struct Coop {
   // dmc_kernels.hip; sums over dofs and rows are group reductions) -----------
   static constexpr int ROUNDS = (NEFC_MAX + G - 1)/G;   // lane rounds needed to cover the rows
   struct Ls { real alpha, dcost, d0, d1; };
-  __device__ void ls_eval(Ls& P, real alpha, real q1, real q2) const {
+  __device__ __forceinline__ void ls_eval(Ls& P, real alpha, real q1, real q2) const {
     real dcost = 0, d0 = 0, d1 = 0;
     for (int r = l; r < nefc; r += G) {
       const real* row = S + off::ROWS + r*CRW;
@@ -1194,7 +1214,7 @@ struct Coop {
   // (fp32) the pass that computes Jv also evaluates the line-search point
   // alpha = 1, the exact Newton step, so the usual iteration needs no further
   // line-search pass.
-  __device__ void solve_newton(real tol) {
+  __device__ __forceinline__ void solve_newton(real tol) {
     const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
     for (int i = l; i < NV; i += G) S[off::MA + i] = mrow_dot(i, off::QACC);
     gsync();
@@ -1234,32 +1254,49 @@ struct Coop {
         for (int t = 0; t < RNV; t++) fc[t] = 0;
         _Pragma("unroll")
         for (int tr = 0; tr < ROUNDS; tr++) {
-          unsigned long long m = visit[tr];
+          // rows that only contribute their force: four at a time, so that the
+          // LDS reads of a group are in flight together
+          unsigned long long m = visit[tr] & ~flipped[tr];
+          while (m) {
+            real f4[4], j4[4][RNV];
+            _Pragma("unroll")
+            for (int u = 0; u < 4; u++) {
+              const bool on = m != 0;
+              const int b = on ? first_bit(m) : 0;
+              m &= m - (on ? 1ull : 0ull);
+              const real* row = S + off::ROWS + (b + tr*G)*CRW;
+              f4[u] = on ? row[CR_F] : R(0);
+              _Pragma("unroll")
+              for (int t = 0; t < RNV; t++) {
+                const int i = l + t*G;
+                j4[u][t] = i < NV ? row[i] : R(0);
+              }
+            }
+            _Pragma("unroll")
+            for (int u = 0; u < 4; u++) {
+              _Pragma("unroll")
+              for (int t = 0; t < RNV; t++) fc[t] += j4[u][t]*f4[u];
+            }
+          }
+          // rows that enter or leave the active set: force and rank-1 change of H
+          m = flipped[tr];
           while (m) {
             const int b = first_bit(m);
             m &= m - 1;
             const real* row = S + off::ROWS + (b + tr*G)*CRW;
             const real f = row[CR_F];
-            if ((flipped[tr] >> b) & 1) {
-              const real D = row[CR_FLIP]*row[CR_D];
-              real jr[NVX];
+            const real D = row[CR_FLIP]*row[CR_D];
+            real jr[NVX];
+            _Pragma("unroll")
+            for (int k = 0; k < NV; k++) jr[k] = row[k];
+            _Pragma("unroll")
+            for (int t = 0; t < RNV; t++) {
+              const int i = l + t*G;
+              const real ji = i < NV ? row[i] : R(0);
+              fc[t] += ji*f;
+              const real s = D*ji;
               _Pragma("unroll")
-              for (int k = 0; k < NV; k++) jr[k] = row[k];
-              _Pragma("unroll")
-              for (int t = 0; t < RNV; t++) {
-                const int i = l + t*G;
-                const real ji = i < NV ? row[i] : R(0);
-                fc[t] += ji*f;
-                const real s = D*ji;
-                _Pragma("unroll")
-                for (int k = 0; k < NV; k++) H.a[t][k] += s*jr[k];
-              }
-            } else {
-              _Pragma("unroll")
-              for (int t = 0; t < RNV; t++) {
-                const int i = l + t*G;
-                fc[t] += (i < NV ? row[i] : R(0))*f;
-              }
+              for (int k = 0; k < NV; k++) H.a[t][k] += s*jr[k];
             }
           }
         }
@@ -1378,7 +1415,7 @@ struct Coop {
 
   // touch sensors (see touch_sensors in dmc_kernels.hip): lane = contact; the
   // row forces CR_F are those of the final iterate
-  __device__ void touch_sensors() {
+  __device__ __forceinline__ void touch_sensors() {
     real acc[NTOUCH > 0 ? NTOUCH : 1];
     _Pragma("unroll")
     for (int s = 0; s < NTOUCH; s++) acc[s] = 0;
@@ -1413,7 +1450,7 @@ struct Coop {
   }
 
   // limits, collision detection, contact Jacobians, reference accelerations
-  __device__ void constraint_rows() {
+  __device__ __forceinline__ void constraint_rows() {
     ncon = 0; nefc = 0;
     limit_rows();
     PROF(PH_LIMIT);
@@ -1423,7 +1460,7 @@ struct Coop {
     PROF(PH_FINISH);
   }
   // wave 1's share of one forward() (DUO): the barriers pair with forward()'s
-  __device__ void forward_rows() {
+  __device__ __forceinline__ void forward_rows() {
     l = opaque(l);
     wsync();
     com_vel();        // ends with a phase boundary: the results are in LDS
@@ -1435,7 +1472,7 @@ struct Coop {
     wsync();
   }
   // wave 1's share of one physics_step() (DUO)
-  __device__ void step_rows() {
+  __device__ __forceinline__ void step_rows() {
     forward_rows();
     if (EULER_OFFLOAD) {
       Rows A;
@@ -1447,7 +1484,7 @@ struct Coop {
   }
 
   // forward dynamics at (qpos, qvel, ctrl): qacc, qfrc_smooth, qfrc_constraint
-  __device__ void forward(bool actuation, real tol) {
+  __device__ __forceinline__ void forward(bool actuation, real tol) {
     PROF(PH_EULER);
     kinematics();
     PROF(PH_KIN);
@@ -1525,7 +1562,7 @@ struct Coop {
   }
 
   // qpos += h * qvel on the configuration manifold (lane = joint); qvel at `v`
-  __device__ void integrate_pos(int v, real h) {
+  __device__ __forceinline__ void integrate_pos(int v, real h) {
     for (int j = l; j < NJNT; j += G) {
       const int qa = jnt_qposadr[j], da = jnt_dofadr[j], jt = jnt_type[j];
       if (jt == JNT_FREE || jt == JNT_BALL) {
@@ -1546,14 +1583,14 @@ struct Coop {
     gsync();
   }
 
-  __device__ void reset_state() {   // mj_resetData
+  __device__ __forceinline__ void reset_state() {   // mj_resetData
     for (int i = l; i < NQ; i += G) S[off::QPOS + i] = R(qpos0[i]);
     for (int i = l; i < NV; i += G) { S[off::QVEL + i] = 0; S[off::WARM + i] = 0; }
     for (int i = l; i < NU; i += G) S[off::CTRL + i] = 0;
     time = 0;
     gsync();
   }
-  __device__ bool check_state() {   // mj_checkPos / mj_checkVel
+  __device__ __forceinline__ bool check_state() {   // mj_checkPos / mj_checkVel
     bool bp = false, bv = false;
     for (int i = l; i < NQ; i += G) bp |= bad(S[off::QPOS + i]);
     for (int i = l; i < NV; i += G) bv |= bad(S[off::QVEL + i]);
@@ -1562,7 +1599,7 @@ struct Coop {
     else if (bv) { warn |= WARN_BADQVEL; reset_state(); }
     return bp || bv;
   }
-  __device__ bool bad_qacc() {
+  __device__ __forceinline__ bool bad_qacc() {
     bool ba = false;
     for (int i = l; i < NV; i += G) ba |= bad(S[off::QACC + i]);
     return gany(ba);
@@ -1571,7 +1608,7 @@ struct Coop {
   // Euler's implicit joint damping: Cholesky factor of M + h D, and
   // GRAD <- (M + h D)^-1 (qfrc_smooth + qfrc_constraint)
   static constexpr bool damped() { return coop_damped(); }
-  __device__ void damped_factor(Rows& A, int panel) {
+  __device__ __forceinline__ void damped_factor(Rows& A, int panel) {
     const real h = R(timestep);
     rows_load(A, off::MM);
     _Pragma("unroll")
@@ -1583,7 +1620,7 @@ struct Coop {
     }
     rows_chol(A, panel);
   }
-  __device__ void damped_solve(const Rows& A) {
+  __device__ __forceinline__ void damped_solve(const Rows& A) {
     real rhs[RNV];
     _Pragma("unroll")
     for (int t = 0; t < RNV; t++) {
@@ -1599,7 +1636,7 @@ struct Coop {
   // one `Physics.step()`; `stale`: acceleration from the position/velocity
   // stage of the reset state, applied to the current state (the first of the
   // cheetah's settle steps, see physics_step in dmc_kernels.hip)
-  __device__ void physics_step(real tol, bool stale = false) {
+  __device__ __forceinline__ void physics_step(real tol, bool stale = false) {
     // nothing derived from the lane index is carried across steps: left alone,
     // the compiler precomputes a few dozen per-lane LDS addresses before the
     // substep loop and then spills them
@@ -1688,7 +1725,7 @@ struct Coop {
     }
   }
 
-  __device__ void observe_stage() {
+  __device__ __forceinline__ void observe_stage() {
     check_state();
     kinematics();
     com_pos();
@@ -1697,7 +1734,7 @@ struct Coop {
   }
 
   // ---- HBM I/O ---------------------------------------------------------------
-  __device__ void load(const DmcArgs& a, int e) {
+  __device__ __forceinline__ void load(const DmcArgs& a, int e) {
     const long long n = a.nenv;
     for (int i = l; i < NQ; i += G) S[off::QPOS + i] = a.qpos[sidx(i, e, n, NQX)];
     for (int i = l; i < NV; i += G) {
@@ -1710,7 +1747,7 @@ struct Coop {
     if (l < (NTOUCH > 0 ? NTOUCH : 1)) S[off::TOUCH + l] = 0;
     for (int i = l; i < NTASKDATA; i += G) S[off::TASKD + i] = a.taskdata[sidx(i, e, n, NTDX)];
   }
-  __device__ void store(const DmcArgs& a, int e) {
+  __device__ __forceinline__ void store(const DmcArgs& a, int e) {
     const long long n = a.nenv;
     for (int i = l; i < NQ; i += G) a.qpos[sidx(i, e, n, NQX)] = S[off::QPOS + i];
     for (int i = l; i < NV; i += G) {
@@ -1721,7 +1758,7 @@ struct Coop {
       if (warn) a.warn[e] |= warn;
     }
   }
-  __device__ void outputs(const DmcArgs& a, int e, bool accumulate) {
+  __device__ __forceinline__ void outputs(const DmcArgs& a, int e, bool accumulate) {
     const long long n = a.nenv;
     if (l == 0) {
       const EnvView V = {S + off::QPOS, S + off::QVEL, S + off::CTRL, S + off::XPOS,

@@ -952,13 +952,34 @@ DEV void geom_pose(const real* G, int g, real* pos, real* mat) {
   for (int k = 0; k < 9; k++) mat[k] = G[12*g + 3 + k];
 }
 
-// static-slot store: rc[cnt] = c without a dynamic index (cnt <= 3)
+// rc[cnt] = c (cnt <= 3).  The several-lanes-per-env build writes it as
+// per-field selects over all four slots: the if-chain below is folded back into
+// a dynamically indexed store by the optimiser, which puts the whole array into
+// scratch memory (2048 waves x 10 KB: more than the L2s hold).  The one-lane
+// build keeps the if-chain: its working set is in registers already, and with
+// forty more live registers the over-budget unrolled fp64 build of the
+// 20-dof known-answer model (2508 spilled VGPRs, never selected by mode
+// "auto") again computed a wrong trajectory on the GPU.
+#ifndef DMC_COOP_BUILD
 DEV void put_slot(RawCon* rc, int cnt, const RawCon& c) {
   if (cnt == 0) rc[0] = c;
   else if (cnt == 1) rc[1] = c;
   else if (cnt == 2) rc[2] = c;
   else rc[3] = c;
 }
+#else
+DEV void put_slot(RawCon* rc, int cnt, const RawCon& c) {
+  DMC_UNROLL
+  for (int s = 0; s < 4; s++) {
+    const bool hit = cnt == s;
+    rc[s].dist = hit ? c.dist : rc[s].dist;
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) rc[s].pos[k] = hit ? c.pos[k] : rc[s].pos[k];
+    DMC_UNROLL
+    for (int k = 0; k < 6; k++) rc[s].frame[k] = hit ? c.frame[k] : rc[s].frame[k];
+  }
+}
+#endif
 
 // narrowphase of static pair p; returns a bit mask of valid contact slots
 DEV int collide_pair(const real* G, int p, RawCon* rc) {

@@ -81,8 +81,9 @@ typedef struct dmc_model_info {
   int abi, real_size, nq, nv, nu, nbody, nobs, nsensordata, ws_per_env, task,
       ncon_max, nefc_max, integrator, npair,
       ntaskdata,     /* per-instance task parameters (DMC_FIELD_TASKDATA rows) */
-      envs_per_block, /* envs per workgroup (one wavefront) of the step kernel */
-      lanes_per_env, /* 1, or the group size of a several-lanes-per-env build */
+      envs_per_block, /* envs per workgroup of the step kernel */
+      lanes_per_env, /* 1, or the group size of a several-lanes-per-env build
+                        (8..64; 128 = one env per workgroup of two wavefronts) */
       env_major;     /* 1: the 2-D state fields are [nenv][k] in HBM (what
                         dmc_batch_device_ptr returns); dmc_batch_read and
                         dmc_batch_set_state present [k][nenv] regardless */
