@@ -162,14 +162,14 @@ def test_several_lanes_per_env_build_matches_oracle(name, nsub, group):
   _assert_fp32_per_step(name, e)
 
 
-@pytest.mark.parametrize('mode', ['unrolled', 'coop'])
-def test_touch_sensors_match_oracle(mode):
+@pytest.mark.parametrize('mode,group', [('unrolled', 64), ('coop', 64), ('coop', 128)])
+def test_touch_sensors_match_oracle(mode, group):
   """mjSENS_TOUCH (hopper toe / heel): the device reading after one physics
   step against the oracle's contact forces and the same ray-in-zone rule,
   evaluated between mj_step2 and mj_step1 as mj_sensorAcc does."""
   model = helpers.load_model('hopper')
   nenv = 48
-  hm, hb = _device_batch(model, helpers.TASKS['hopper'], 'f64', nenv, mode)
+  hm, hb = _device_batch(model, helpers.TASKS['hopper'], 'f64', nenv, mode, group=group)
   qpos, qvel = helpers.initial_states(model, 'hopper', nenv, seed=2)
   om, datas = _oracle_envs(model, qpos, qvel)
   rs = np.random.RandomState(0)
@@ -196,7 +196,8 @@ def test_touch_sensors_match_oracle(mode):
   hb.free()
 
 
-def test_touch_after_reset_of_a_hopper_in_contact():
+@pytest.mark.parametrize('kernel', [{}, {'build_mode': 'coop', 'group': 128}])
+def test_touch_after_reset_of_a_hopper_in_contact(kernel):
   """`after_reset` (what produces the FIRST TimeStep's observation): the
   reference runs mj_forward with actuation disabled there (engine.py:283-295),
   so the touch sensors hold the contact forces of the start pose.  Poses with
@@ -204,7 +205,7 @@ def test_touch_after_reset_of_a_hopper_in_contact():
   counts contacts -- against the oracle's forward pass."""
   nenv = 64
   env = suite.load('hopper', 'stand', task_kwargs={'random': 3},
-                   environment_kwargs={'batch_size': nenv, 'precision': 'f64'})
+                   environment_kwargs=dict(kernel, batch_size=nenv, precision='f64'))
   ts = env.reset()
   assert ts.first() and ts.observation['touch'].shape == (nenv, 2)
   physics, task = env.physics, env.task
@@ -936,20 +937,27 @@ def test_vec_env_numpy_and_torch_modes():
   ref.close()
 
 
-@pytest.mark.parametrize('nenv', [1, 63, 65, 1000])
-def test_ragged_batch_sizes_match_full_batches(nenv):
+@pytest.mark.parametrize('name,mode,group,nsub,nenv', [
+    ('cheetah', 'auto', 64, 1, 1), ('cheetah', 'auto', 64, 1, 63),
+    ('cheetah', 'auto', 64, 1, 65), ('cheetah', 'auto', 64, 1, 1000),
+    # several lanes per env: env = workgroup, permuted so that every XCD works
+    # on a contiguous range of envs -- a bijection for any workgroup count
+    ('humanoid', 'coop', 128, 5, 1), ('humanoid', 'coop', 128, 5, 7),
+    ('humanoid', 'coop', 128, 5, 1003), ('cheetah', 'coop', 32, 1, 1001)])
+def test_ragged_batch_sizes_match_full_batches(name, mode, group, nsub, nenv):
   """Partial last workgroup (the coalesced observation store and the early
-  exit of surplus lanes): env i of a ragged batch == env i of a 1024 batch."""
-  model = helpers.load_model('cheetah')
-  qpos, qvel = helpers.initial_states(model, 'cheetah', 1024, seed=5)
+  exit of surplus lanes) and any number of workgroups: env i of a ragged
+  batch == env i of a 1024 batch, bit for bit."""
+  model = helpers.load_model(name)
+  qpos, qvel = helpers.initial_states(model, name, 1024, seed=5)
   rs = np.random.RandomState(3)
   ctrl = rs.uniform(-1, 1, (6, 1024, model.nu))
   outs = []
   for n in (1024, nenv):
-    hm, hb = _device_batch(model, codegen.TASK_CHEETAH, 'f32', n)
+    hm, hb = _device_batch(model, helpers.TASKS[name], 'f32', n, mode, group=group)
     hb.set_state(qpos[:n].T, qvel[:n].T)
     for t in range(6):
-      hb.step_host(ctrl[t, :n], 1)
+      hb.step_host(ctrl[t, :n], nsub)
     outs.append((hb.read(W.FIELD_QPOS)[:, :nenv], hb.read(W.FIELD_OBS)[:nenv],
                  hb.read(W.FIELD_REWARD)[:nenv], hb.read(W.FIELD_RETURN)[:nenv]))
     hb.free()
