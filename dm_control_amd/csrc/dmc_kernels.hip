@@ -916,8 +916,18 @@ DEV int sphere_sphere(RawCon* c, real margin, const real* p1, const real* p2,
   const real dist = len - r1 - r2;
   if (dist > margin) return 0;
   c->dist = dist;
+#ifdef DMC_COOP_BUILD
+  // selects per component: as an if / else over a loop LLVM turned the stores
+  // into a dynamically indexed stack slot (scratch traffic from 2048 waves).
+  // Only in the several-lanes build, for the reason given at put_slot().
+  const bool apart = !(len < DMC_MINVAL);
+  c->frame[0] = apart ? dif[0]/len : R(1);
+  c->frame[1] = apart ? dif[1]/len : R(0);
+  c->frame[2] = apart ? dif[2]/len : R(0);
+#else
   if (len < DMC_MINVAL) { c->frame[0] = 1; c->frame[1] = c->frame[2] = 0; }
   else for (int k = 0; k < 3; k++) c->frame[k] = dif[k]/len;
+#endif
   DMC_UNROLL
   for (int k = 0; k < 3; k++) {
     c->pos[k] = p1[k] + c->frame[k]*(r1 + R(0.5)*dist);
