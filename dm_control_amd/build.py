@@ -118,6 +118,10 @@ def _within_spill_budget(spills):
 def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
              keep_temps, source='dmc_kernels.hip', kernel='dmc_step'):
   key = os.path.basename(out)[4:-6]
+  if os.environ.get('DMC_BUILD_LOG'):     # which code objects were not pre-built
+    with open(os.environ['DMC_BUILD_LOG'], 'a') as f:
+      f.write('%s task=%d %s ncon_max=%r flags=%r unroll=%r nv=%d nbody=%d\n' % (
+          source, task, precision, ncon_max, tuple(extra_flags), unroll, model.nv, model.nbody))
   header = os.path.join(_BUILD, 'model_%s.h' % key)
   with open(header, 'w') as f:
     f.write(codegen.generate_header(model, task, ncon_max, unroll=unroll))
