@@ -190,6 +190,30 @@ OSCILLATOR = """
 </mujoco>
 """
 
+# A puck on two orthogonal sliders pulled by two motors through fixed tendons
+# that mix the sliders (the transmission of suite/point_mass.xml); per-joint
+# damping, no contacts: every dof follows a closed-form discrete map.
+TENDON_PUCK = """
+<mujoco>
+  <option timestep="0.01"/>
+  <worldbody>
+    <body name="puck" pos="0 0 0.1">
+      <joint name="x" type="slide" axis="1 0 0" damping="0.7"/>
+      <joint name="y" type="slide" axis="0 1 0" damping="0.2"/>
+      <geom type="sphere" size="0.05" mass="1.5"/>
+    </body>
+  </worldbody>
+  <tendon>
+    <fixed name="t1"><joint joint="x" coef="0.8"/><joint joint="y" coef="-0.6"/></fixed>
+    <fixed name="t2"><joint joint="x" coef="0.3"/><joint joint="y" coef="0.9"/></fixed>
+  </tendon>
+  <actuator>
+    <motor name="a1" tendon="t1" gear="2" ctrllimited="true" ctrlrange="-1 1"/>
+    <motor name="a2" tendon="t2" gear="0.5" ctrllimited="true" ctrlrange="-1 1"/>
+  </actuator>
+</mujoco>
+"""
+
 CAPSULE_PAIR = """
 <mujoco>
   <option gravity="0 0 0"/>
@@ -258,4 +282,5 @@ def closed_form_models():
   c.opt.integrator = 0
   out['cartpole_at_limit'] = (c, 'auto')
   out['cube_with_touch'] = (compiler.from_xml_string(CUBE_WITH_TOUCH), 'auto')
+  out['tendon_puck'] = (compiler.from_xml_string(TENDON_PUCK), 'auto')
   return out

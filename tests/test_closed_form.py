@@ -228,6 +228,35 @@ def test_implicit_joint_damping_matches_its_discrete_map(kind):
   np.testing.assert_allclose([q[0], qd[0]], [x, v], rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize('kind', KINDS)
+def test_fixed_tendon_transmission_matches_its_discrete_map(kind):
+  """Motors acting through fixed tendons that mix two sliders (the transmission
+  of suite/point_mass.xml): the generalised force is sum_u gear_u ctrl_u C[u][j],
+  controls are clamped to ctrlrange, and with the implicit joint damping of
+  the Euler integrator each slider follows v' = (m v + h f_j)/(m + h d_j),
+  q' = q + h v' exactly.  Independent of the oracle's reading of
+  mj_transmission / mj_fwdActuation."""
+  model, _ = MODELS['tendon_puck']
+  m, h = 1.5, 0.01
+  d = np.array([0.7, 0.2])
+  gear = np.array([2.0, 0.5])
+  C = np.array([[0.8, -0.6], [0.3, 0.9]])        # tendon u = sum_j C[u][j] q_j
+  assert abs(model.body_mass[1] - m) < 1e-12 and model.opt.timestep == h
+  q = np.array([0.1, -0.2])
+  v = np.array([0.5, 0.3])
+  s = _stepper(kind, 'tendon_puck', q, v)
+  rs = np.random.RandomState(0)
+  for _ in range(400):
+    ctrl = rs.uniform(-1.5, 1.5, 2)                # beyond ctrlrange: clamped
+    f = (gear*np.clip(ctrl, -1, 1)) @ C
+    v = (m*v + h*f)/(m + h*d)
+    q = q + h*v
+    s.step(ctrl)
+  qs, vs = s.state()
+  np.testing.assert_allclose(qs, q, rtol=0, atol=1e-12)
+  np.testing.assert_allclose(vs, v, rtol=0, atol=1e-12)
+
+
 def _impedance(solimp, r):
   d0, dmax, width, mid, power = solimp
   x = min(abs(r)/width, 1.0)
