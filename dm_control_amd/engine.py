@@ -391,13 +391,11 @@ class Physics(_control.Physics):
     self._profile_calls = 0
     self._build_mode = build_mode or self._BUILD_MODE
     self._group = group or self._GROUP
-    if group is None and precision == 'f64' and self._group == 128:
-      self._group = 64          # fp64 rows need the registers of a whole SIMD lane slot
     if build_mode is None and self._build_mode == 'auto' and precision != 'mixed':
       for max_batch, lanes in self._COOP_POLICY:
         if self._batch_size <= max_batch:
           if lanes == 128 and precision == 'f64':
-            lanes = 64
+            lanes = 64    # measured for the humanoid only (fp64: -19 %), not for the small models
           self._build_mode, self._group = 'coop', lanes
           break
     path = build.build_model(

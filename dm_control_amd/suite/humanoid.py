@@ -62,7 +62,7 @@ class Physics(engine.Physics):
   # 27 dofs: one env per 64-lane group with its working set in LDS
   # (csrc/dmc_coop.hip); the one-lane build spills the 27 x 27 matrices
   _BUILD_MODE = 'coop'
-  _GROUP = 128   # + a second wavefront per env for the constraint rows (fp32)
+  _GROUP = 128   # + a second wavefront per env for the constraint rows (fp32 and fp64)
 
   def torso_upright(self):
     return self.named.data.xmat['torso', 'zz']
