@@ -394,8 +394,6 @@ class Physics(_control.Physics):
     if build_mode is None and self._build_mode == 'auto' and precision != 'mixed':
       for max_batch, lanes in self._COOP_POLICY:
         if self._batch_size <= max_batch:
-          if lanes == 128 and precision == 'f64':
-            lanes = 64    # measured for the humanoid only (fp64: -19 %), not for the small models
           self._build_mode, self._group = 'coop', lanes
           break
     path = build.build_model(

@@ -15,17 +15,18 @@ name = sys.argv[1]
 batches = [int(x) for x in sys.argv[2:]] or [256, 1024, 2048, 4096, 8192]
 model = helpers.load_model(name)
 nsub = {'cheetah': 1, 'walker': 10, 'hopper': 4, 'humanoid': 5}[name]
+PREC = os.environ.get('DMC_SWEEP_PRECISION', 'f32')
 VARIANTS = (('one env per lane', 'auto', 64, ()),
-            ('64 lanes x 2 waves', 'coop', 64, ()),
-            ('64 lanes', 'coop', 64, ('-DDMC_COOP_DUO=0',)),
+            ('64 lanes x 2 waves', 'coop', 128, ()),
+            ('64 lanes', 'coop', 64, ()),
             ('32 lanes', 'coop', 32, ()))
 for B in batches:
-  line = '%s B=%d:' % (name, B)
+  line = '%s %s B=%d:' % (name, PREC, B)
   for label, mode, group, flags in VARIANTS:
     if name == 'humanoid' and mode == 'auto' and B > 1024:
       continue
     try:
-      path = build.build_model(model, helpers.TASKS[name], 'f32', mode=mode, group=group,
+      path = build.build_model(model, helpers.TASKS[name], PREC, mode=mode, group=group,
                                extra_flags=flags)
     except Exception as e:   # LDS does not fit
       line += '  %s n/a' % label; continue
