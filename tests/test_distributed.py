@@ -79,3 +79,51 @@ def test_gather_is_identity_without_process_group():
   import torch
   x = torch.arange(4.0)
   assert distributed.gather_episode_returns(x) is x
+
+
+def _bench(*argv, env=None):
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  e = dict(os.environ if env is None else env)
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+    e.pop(k, None)
+  return subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + list(argv),
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e,
+                        timeout=280, universal_newlines=True)
+
+
+@pytest.mark.timeout(300)
+def test_bench_launches_its_own_ranks():
+  """`python bench.py --gpus N` as the driver calls it (no torchrun): the parent
+  starts N ranks itself; --dry-run takes the launcher, the sharding and the
+  reporting all-gather with gloo and no kernels (scripts/vec_env.py:396-465 is
+  the reference's fan-out)."""
+  import json
+  for argv, total, shard0 in (
+      (['--gpus', '2', '--dry-run'], 16384, [0, 8192]),
+      (['--gpus', '3', '--dry-run', '--global-batch', '11'], 11, [0, 4])):
+    proc = _bench(*argv)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = proc.stdout.strip().splitlines()
+    assert len(lines) == 1, proc.stdout            # ONE JSON line on stdout
+    line = json.loads(lines[0])
+    assert line['dry_run'] and line['gather_ok']
+    assert line['world_size_seen'] == int(argv[1]) == line['n_gpus']
+    assert line['global_batch'] == line['gathered_returns'] == total
+    assert line['rank0_shard'] == shard0
+    assert line['scaling'] == ('strong' if '--global-batch' in argv else 'weak')
+
+
+@pytest.mark.timeout(300)
+def test_bench_launcher_propagates_a_failing_rank():
+  """A rank that dies (here: asked for more ranks than the launcher started)
+  must turn into a non-zero exit code of the parent, not a hang."""
+  env = dict(os.environ, RANK='0')      # pretend to be a rank of a 1-rank world
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  proc = subprocess.run([sys.executable, os.path.join(root, 'bench.py'),
+                         '--gpus', '2', '--dry-run'], env=env, timeout=200,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+  assert proc.returncode != 0
