@@ -33,23 +33,20 @@ class Environment(dm_env.Environment):
   def __init__(self, physics, task, time_limit=float('inf'),
                control_timestep=None, n_sub_steps=None,
                flat_observation=False):
-    self._task = task
-    self._physics = physics
-    self._flat_observation = flat_observation
-    if n_sub_steps is not None and control_timestep is not None:
-      raise ValueError('Both n_sub_steps and control_timestep were supplied.')
-    elif n_sub_steps is not None:
-      self._n_sub_steps = n_sub_steps
-    elif control_timestep is not None:
-      self._n_sub_steps = compute_n_steps(control_timestep,
-                                          self._physics.timestep())
+    self._physics, self._task = physics, task
+    self._flat_observation = bool(flat_observation)
+    dt = physics.timestep()
+    if control_timestep is None:
+      substeps = 1 if n_sub_steps is None else n_sub_steps
+    elif n_sub_steps is None:
+      substeps = compute_n_steps(control_timestep, dt)
     else:
-      self._n_sub_steps = 1
-    if time_limit == float('inf'):
-      self._step_limit = float('inf')
-    else:
-      self._step_limit = time_limit / (
-          self._physics.timestep() * self._n_sub_steps)
+      raise ValueError('pass either control_timestep or n_sub_steps, not both '
+                       '(got {} and {})'.format(control_timestep, n_sub_steps))
+    self._n_sub_steps = substeps
+    # a float on purpose (compared with >=): time_limit / (dt * n_sub), the
+    # expression of rl/control.py:72-73; inf / x stays inf
+    self._step_limit = time_limit / (dt * substeps)
     self._step_count = 0
     self._reset_next_step = True
 
@@ -130,17 +127,18 @@ class Environment(dm_env.Environment):
 
 
 def compute_n_steps(control_timestep, physics_timestep, tolerance=1e-8):
-  """Number of physics steps per control step (control.py:164-190)."""
+  """Physics steps per control step (the contract of rl/control.py:164-190):
+  the ratio must be a whole number >= 1 to within `tolerance`."""
+  ratio = control_timestep / physics_timestep
+  whole = int(round(ratio))
   if control_timestep < physics_timestep:
-    raise ValueError(
-        'Control timestep ({}) cannot be smaller than physics timestep ({}).'.
-        format(control_timestep, physics_timestep))
-  if abs((control_timestep / physics_timestep - round(
-      control_timestep / physics_timestep))) > tolerance:
-    raise ValueError(
-        'Control timestep ({}) must be an integer multiple of physics timestep '
-        '({})'.format(control_timestep, physics_timestep))
-  return int(round(control_timestep / physics_timestep))
+    raise ValueError('a control step of {} s is shorter than one physics step '
+                     '({} s)'.format(control_timestep, physics_timestep))
+  if abs(ratio - whole) > tolerance:
+    raise ValueError('a control step of {} s is {} physics steps of {} s; it '
+                     'has to be a whole number of them'.format(
+                         control_timestep, ratio, physics_timestep))
+  return whole
 
 
 def _spec_from_observation(observation):
@@ -162,12 +160,11 @@ def flatten_observation(observation, output_key=FLAT_OBSERVATION_KEY):
   ravelled to 1-D, a batched [B, ...] leaf to [B, -1].
   """
   if not isinstance(observation, collections.abc.MutableMapping):
-    raise ValueError('Can only flatten dict-like observations.')
-  if isinstance(observation, collections.OrderedDict):
-    keys = observation.keys()
-  else:
-    keys = sorted(observation.keys())
-  leaves = [np.asarray(observation[key]) for key in keys]
+    raise ValueError('flatten_observation takes a dict of arrays, got a {}'
+                     .format(type(observation).__name__))
+  ordered = isinstance(observation, collections.OrderedDict)
+  names = list(observation) if ordered else sorted(observation)
+  leaves = [np.asarray(observation[name]) for name in names]
   batch = getattr(observation, 'batch_size', None)
   if batch is None:
     arrays = [leaf.ravel() for leaf in leaves]

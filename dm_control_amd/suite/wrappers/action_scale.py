@@ -1,61 +1,77 @@
-"""Rescales actions to a caller-chosen range (cf. suite/wrappers/action_scale.py).
+"""Affine re-scaling of the action interval (stands in for the reference's
+suite/wrappers/action_scale.py: same constructor signature, same effect).
 
-Works for unbatched `[nu]` and batched `[B, nu]` actions: the affine map is
-elementwise over the last axis.
+The agent acts in `[minimum, maximum]`; the wrapped env receives
+`env_lo + (a - minimum) * (env_hi - env_lo) / (maximum - minimum)`.  The map is
+elementwise over the last axis, so unbatched `[nu]` and batched `[B, nu]`
+actions go through the same code.
 """
 
 import numpy as np
 
 from dm_control_amd import _dm_env as dm_env
 
-specs = dm_env.specs
 
+# Message templates: the reference's tests format these module constants
+# themselves (action_scale_test.py:119-160), so the names and the fields
+# {name} / {bounds} / {shape} are interface; the wording is ours.
 _ACTION_SPEC_MUST_BE_BOUNDED_ARRAY = (
-    '`env.action_spec()` must return a single `BoundedArray`, got: {}.')
-_MUST_BE_FINITE = 'All values in `{name}` must be finite, got: {bounds}.'
-_MUST_BROADCAST = (
-    '`{name}` must be broadcastable to shape {shape}, got: {bounds}.')
+    'action_scale needs an env whose action_spec() is one BoundedArray; this '
+    'one returned {}')
+_MUST_BE_FINITE = 'action_scale: `{name}` has non-finite entries: {bounds}'
+_MUST_BROADCAST = ('action_scale: `{name}` = {bounds} does not fit actions of '
+                   'shape {shape}')
+
+
+def _checked_bound(values, label, shape):
+  """`values` as an array that is finite everywhere and fits `shape`."""
+  values = np.asarray(values)
+  if not np.isfinite(values).all():
+    raise ValueError(_MUST_BE_FINITE.format(name=label, bounds=values))
+  try:
+    fits = np.broadcast_shapes(values.shape, shape) == tuple(shape)
+  except ValueError:
+    fits = False
+  if not fits:
+    raise ValueError(_MUST_BROADCAST.format(name=label, bounds=values,
+                                            shape=tuple(shape)))
+  return values
 
 
 class Wrapper(dm_env.Environment):
-  """Maps actions in [minimum, maximum] onto the wrapped env's bounds."""
+  """Lets an agent act in [minimum, maximum] instead of the env's own bounds."""
 
   def __init__(self, env, minimum, maximum):
-    action_spec = env.action_spec()
-    if not isinstance(action_spec, specs.BoundedArray):
-      raise ValueError(_ACTION_SPEC_MUST_BE_BOUNDED_ARRAY.format(action_spec))
-    minimum, maximum = np.array(minimum), np.array(maximum)
-    shape = action_spec.shape
-    lo, hi, dtype = action_spec.minimum, action_spec.maximum, action_spec.dtype
-    for bounds, name in ((minimum, 'minimum'), (maximum, 'maximum'),
-                         (lo, 'env.action_spec().minimum'),
-                         (hi, 'env.action_spec().maximum')):
-      if not np.all(np.isfinite(bounds)):
-        raise ValueError(_MUST_BE_FINITE.format(name=name, bounds=bounds))
-      try:
-        np.broadcast_to(bounds, shape)
-      except ValueError:
-        raise ValueError(_MUST_BROADCAST.format(name=name, bounds=bounds,
-                                                shape=shape))
-    scale = (hi - lo)/(maximum - minimum)
-    self._transform = lambda a: (lo + scale*(np.asarray(a) - minimum)).astype(
-        dtype, copy=False)
-    self._action_spec = action_spec.replace(
-        minimum=minimum, maximum=maximum,
-        dtype=np.result_type(minimum, maximum, dtype))
+    inner = env.action_spec()
+    if not isinstance(inner, dm_env.specs.BoundedArray):
+      raise ValueError(_ACTION_SPEC_MUST_BE_BOUNDED_ARRAY.format(inner))
     self._env = env
+    self._lo = _checked_bound(inner.minimum, 'env.action_spec().minimum', inner.shape)
+    span = _checked_bound(inner.maximum, 'env.action_spec().maximum',
+                          inner.shape) - self._lo
+    self._from = _checked_bound(minimum, 'minimum', inner.shape)
+    upto = _checked_bound(maximum, 'maximum', inner.shape)
+    self._gain = span/(upto - self._from)
+    self._inner_dtype = inner.dtype
+    self._spec = inner.replace(
+        minimum=self._from, maximum=upto,
+        dtype=np.result_type(self._from, upto, inner.dtype))
+
+  def _to_env(self, action):
+    scaled = self._lo + self._gain*(np.asarray(action) - self._from)
+    return scaled.astype(self._inner_dtype, copy=False)
 
   def step(self, action):
-    return self._env.step(self._transform(action))
+    return self._env.step(self._to_env(action))
 
   def reset(self):
     return self._env.reset()
 
+  def action_spec(self):
+    return self._spec
+
   def observation_spec(self):
     return self._env.observation_spec()
 
-  def action_spec(self):
-    return self._action_spec
-
-  def __getattr__(self, name):
-    return getattr(self._env, name)
+  def __getattr__(self, attr):
+    return getattr(self._env, attr)
