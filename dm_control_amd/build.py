@@ -5,6 +5,7 @@ the artefacts travel to the GPU box with the repository snapshot.  hipcc
 cross-compiles for gfx950 without a GPU present.
 """
 
+import contextlib
 import hashlib
 import os
 import shutil
@@ -66,6 +67,13 @@ def build_library(force=False):
 # per-lane arrays are explicit scratch objects instead of register spills.
 MAX_VGPR_SPILLS = 128
 MAX_SGPR_SPILLS = 128
+# The several-lanes kernel (csrc/dmc_coop.hip) keeps per-env data in LDS and its
+# uniform address arithmetic in SGPRs: every suite build spills 136-386 SGPRs
+# (to VGPR lanes, no scratch traffic) and at most 7 VGPRs, and all of them are
+# parity-tested per step against the oracle.  What the guard must refuse there
+# is the same thing as above: builds that spill VGPRs wholesale to scratch
+# (the 62-dof soccer walker: 1652 fp32 / 6552 fp64).
+COOP_MAX_SGPR_SPILLS = 640
 
 
 # fp32 builds: v_rcp / v_rsq based division and sqrt (<= 2.5 ulp) instead of the
@@ -110,9 +118,43 @@ def _spills(remarks, kernel='dmc_step'):
   return vg, sg
 
 
-def _within_spill_budget(spills):
+_OVERBUDGET_MSG = (
+    'the unrolled build of this model spills %%s (VGPR, SGPR) registers, beyond '
+    'the budget of %d / %d within which this kind of build is trusted '
+    '(DESIGN.md 3.4: an over-budget build has produced wrong results on '
+    'gfx950); use mode="auto" / "rolled" / "coop", or set '
+    '$DMC_ALLOW_OVERBUDGET=1 to build it anyway' % (MAX_VGPR_SPILLS, MAX_SGPR_SPILLS))
+
+
+_COOP_OVERBUDGET_MSG = (
+    'the several-lanes build of this model spills %%s (VGPR, SGPR) registers '
+    '(budget %d / %d); set $DMC_ALLOW_OVERBUDGET=1 to build it anyway'
+    % (MAX_VGPR_SPILLS, COOP_MAX_SGPR_SPILLS))
+
+
+def _allow_overbudget():
+  """Explicit override for experiments and the canary test."""
+  return os.environ.get('DMC_ALLOW_OVERBUDGET') == '1'
+
+
+@contextlib.contextmanager
+def allow_overbudget():
+  """`with build.allow_overbudget():` -- builds inside may exceed the spill
+  budget (the canary test and tools/spill_hazard/ only; never the product)."""
+  prev = os.environ.get('DMC_ALLOW_OVERBUDGET')
+  os.environ['DMC_ALLOW_OVERBUDGET'] = '1'
+  try:
+    yield
+  finally:
+    if prev is None:
+      del os.environ['DMC_ALLOW_OVERBUDGET']
+    else:
+      os.environ['DMC_ALLOW_OVERBUDGET'] = prev
+
+
+def _within_spill_budget(spills, max_sgpr=MAX_SGPR_SPILLS):
   return (spills is not None and spills[0] <= MAX_VGPR_SPILLS
-          and spills[1] <= MAX_SGPR_SPILLS)
+          and spills[1] <= max_sgpr)
 
 
 def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
@@ -266,9 +308,20 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     out = os.path.join(_BUILD, 'dmc_%s.hsaco' % model_key(
         model, task, precision, ncon_max, flags, True))
     if force or not os.path.exists(out):
-      _compile(model, task, precision, ncon_max, flags, True, out, keep_temps,
-               source='dmc_coop.hip')
+      spills = _compile(model, task, precision, ncon_max, flags, True, out,
+                        keep_temps, source='dmc_coop.hip')
+      # the several-lanes kernel keeps its working set in LDS; a build that
+      # spills beyond the budget is as untrusted as an over-budget unrolled one
+      ok = _within_spill_budget(spills, COOP_MAX_SGPR_SPILLS)
+      if not ok and not _allow_overbudget():
+        os.remove(out + '.tmp')
+        raise RuntimeError(_COOP_OVERBUDGET_MSG % (spills,))
       os.replace(out + '.tmp', out)
+      with open(out + ('.ok' if ok else '.overbudget'), 'w') as f:
+        f.write('%r' % (spills,))
+    elif os.path.exists(out + '.overbudget') and not _allow_overbudget():
+      with open(out + '.overbudget') as f:
+        raise RuntimeError(_COOP_OVERBUDGET_MSG % f.read().strip())
     return out
 
   def path(unroll):
@@ -278,8 +331,12 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
   vetted = path(True) + '.ok'         # spill counts recorded and within budget
   if not force:
     if mode != 'rolled' and os.path.exists(path(True)) and (
-        mode == 'unrolled' or os.path.exists(vetted)):
+        os.path.exists(vetted) or (mode == 'unrolled' and _allow_overbudget())):
       return path(True)
+    over = path(True) + '.overbudget'   # built once with the override: spills known
+    if mode == 'unrolled' and os.path.exists(over) and not _allow_overbudget():
+      with open(over) as f:
+        raise RuntimeError(_OVERBUDGET_MSG % f.read().strip())
     if mode != 'unrolled' and os.path.exists(path(False)) and (
         mode == 'rolled' or os.path.exists(marker)):
       return path(False)
@@ -288,8 +345,14 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     spills = _compile(model, task, precision, ncon_max, extra_flags, True, out,
                       keep_temps)
     ok = _within_spill_budget(spills)
+    if mode == 'unrolled' and not ok and not _allow_overbudget():
+      os.remove(out + '.tmp')
+      raise RuntimeError(_OVERBUDGET_MSG % (spills,))
     if mode == 'unrolled' or ok:
       os.replace(out + '.tmp', out)
+      if not ok:
+        with open(out + '.overbudget', 'w') as f:
+          f.write('%r' % (spills,))
       if ok:
         with open(vetted, 'w') as f:
           f.write('vgpr spills %d, sgpr spills %d\n' % spills)

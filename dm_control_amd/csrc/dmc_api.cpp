@@ -168,29 +168,55 @@ struct Hiprtc {
   decltype(&hiprtcGetErrorString) error_string = nullptr;
 };
 
-const Hiprtc* hiprtc() {
-  static Hiprtc rtc;
-  static bool tried = false;
-  if (tried) return rtc.lib ? &rtc : nullptr;
-  tried = true;
-  for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
-    rtc.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-    if (rtc.lib) break;
-  }
-  if (!rtc.lib) return nullptr;
+// Opens libhiprtc once (thread-safe: a function-local static is initialised
+// exactly once) and keeps the reason when that fails -- dlerror() is cleared by
+// the call that reads it and overwritten by any later dl* call, so it is read
+// once, right where the failure happened.
+struct HiprtcOnce {
+  Hiprtc rtc{};
+  std::string why;
+  HiprtcOnce() {
+    for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+      rtc.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (rtc.lib) break;
+      const char* e = dlerror();
+      if (e) why = e;
+    }
+    if (!rtc.lib) {
+      if (why.empty()) why = "dlopen failed";
+      return;
+    }
+    why.clear();
 #define DMC_SYM(field, symbol)                                              \
-  rtc.field = (decltype(rtc.field))dlsym(rtc.lib, #symbol);                  \
-  if (!rtc.field) { dlclose(rtc.lib); rtc.lib = nullptr; return nullptr; }
-  DMC_SYM(create, hiprtcCreateProgram)
-  DMC_SYM(compile, hiprtcCompileProgram)
-  DMC_SYM(log_size, hiprtcGetProgramLogSize)
-  DMC_SYM(log, hiprtcGetProgramLog)
-  DMC_SYM(code_size, hiprtcGetCodeSize)
-  DMC_SYM(code, hiprtcGetCode)
-  DMC_SYM(destroy, hiprtcDestroyProgram)
-  DMC_SYM(error_string, hiprtcGetErrorString)
+    if (rtc.lib) {                                                          \
+      rtc.field = (decltype(rtc.field))dlsym(rtc.lib, #symbol);             \
+      if (!rtc.field) {                                                     \
+        const char* e = dlerror();                                          \
+        why = e ? e : "symbol " #symbol " missing";                         \
+        dlclose(rtc.lib);                                                   \
+        rtc.lib = nullptr;                                                  \
+      }                                                                     \
+    }
+    DMC_SYM(create, hiprtcCreateProgram)
+    DMC_SYM(compile, hiprtcCompileProgram)
+    DMC_SYM(log_size, hiprtcGetProgramLogSize)
+    DMC_SYM(log, hiprtcGetProgramLog)
+    DMC_SYM(code_size, hiprtcGetCodeSize)
+    DMC_SYM(code, hiprtcGetCode)
+    DMC_SYM(destroy, hiprtcDestroyProgram)
+    DMC_SYM(error_string, hiprtcGetErrorString)
 #undef DMC_SYM
-  return &rtc;
+  }
+};
+
+const HiprtcOnce* hiprtc_once() {
+  static const HiprtcOnce once;
+  return &once;
+}
+
+const Hiprtc* hiprtc() {
+  const HiprtcOnce* o = hiprtc_once();
+  return o->rtc.lib ? &o->rtc : nullptr;
 }
 
 }  // namespace
@@ -209,7 +235,7 @@ int dmc_model_compile(const char* source, const char* source_name,
   const Hiprtc* rtc = hiprtc();
   if (!rtc)
     return fail("dmc_model_compile: the HIP runtime-compilation library "
-                "(libhiprtc) is not available: %s", dlerror() ? dlerror() : "symbols missing");
+                "(libhiprtc) is not available: %s", hiprtc_once()->why.c_str());
   hiprtcProgram prog = nullptr;
   hiprtcResult rc = rtc->create(&prog, source, source_name ? source_name : "dmc_model.hip",
                                 nheaders, const_cast<const char**>(header_texts),

@@ -970,7 +970,7 @@ DEV void geom_pose(const real* G, int g, real* pos, real* mat) {
 // forty more live registers the over-budget unrolled fp64 build of the
 // 20-dof known-answer model (2508 spilled VGPRs, never selected by mode
 // "auto") again computed a wrong trajectory on the GPU.
-#ifndef DMC_COOP_BUILD
+#if !defined(DMC_COOP_BUILD) && !defined(DMC_SELECT_SLOTS)   // -DDMC_SELECT_SLOTS: tools/spill_hazard/
 DEV void put_slot(RawCon* rc, int cnt, const RawCon& c) {
   if (cnt == 0) rc[0] = c;
   else if (cnt == 1) rc[1] = c;

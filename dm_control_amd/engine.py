@@ -636,7 +636,10 @@ class Physics(_control.Physics):
     control a step without a new action re-applies; the per-instance task data
     (reacher target, point_mass directions) is part of the dynamics and of the
     reward; episode_return and the warning mask complete the bookkeeping.  A
-    restored batch continues bit-for-bit under the same actions.  `step_count`
+    restored f32 or f64 batch continues bit-for-bit under the same actions.  A
+    precision='mixed' batch restores the fp32 words of qpos/qvel only (the low
+    words of its fp64 state live in the kernel's workspace and restart at
+    zero), so it continues to fp32 rounding, not bit-for-bit.  `step_count`
     (e.g. `Environment.step_count`) is stored for the caller's episode logic.
     """
     b = self._batch
@@ -651,6 +654,13 @@ class Physics(_control.Physics):
     """Restores a state written by `save_checkpoint` (same model, precision and
     batch size); returns the stored step count (None if none was stored)."""
     with np.load(self._checkpoint_path(path), allow_pickle=False) as z:
+      needed = ['model_hash', 'precision', 'step_count'] + [
+          name for name, _ in self._CHECKPOINT_FIELDS]
+      missing = [name for name in needed if name not in z.files]
+      if missing:
+        raise ValueError(
+            'checkpoint {} lacks {} (written by an older version that stored '
+            'qpos/qvel/qacc_warmstart/time only?)'.format(path, ', '.join(missing)))
       if str(z['model_hash']) != self.model.content_hash():
         raise ValueError('checkpoint was written for a different model')
       if str(z['precision']) != self._precision:

@@ -18,6 +18,8 @@ normal defined by rounding in ANY implementation) are excluded from the
 per-step fp32 statistics.
 """
 
+import contextlib
+
 import numpy as np
 import pytest
 
@@ -140,6 +142,17 @@ def test_fp32_build_matches_oracle_per_step(name, nsub):
   _assert_fp32_per_step(name, e)
 
 
+@pytest.mark.parametrize('name', ['cartpole', 'cheetah'])
+def test_mixed_build_matches_oracle_per_step(name):
+  """precision='mixed' (fp32 arithmetic, qpos/qvel carried as fp64 (high, low)
+  pairs; one-env-per-lane kernel): a step from an uploaded state is an fp32
+  step -- same per-step bounds as the fp32 build."""
+  e = _teacher_forced(name, 'mixed', nenv=128, steps=12, nsub=1)
+  print('OBSERVED mixed per-step %s: median %.2e p99 %.2e max %.2e'
+        % (name, np.median(e), np.percentile(e, 99), e.max()))
+  _assert_fp32_per_step(name, e)
+
+
 @pytest.mark.parametrize('name,nsub,group', [
     ('cartpole', 1, 64), ('cheetah', 1, 64), ('walker', 10, 64),
     ('hopper', 4, 64), ('point_mass', 1, 64), ('cheetah', 1, 32),
@@ -162,14 +175,18 @@ def test_several_lanes_per_env_build_matches_oracle(name, nsub, group):
   _assert_fp32_per_step(name, e)
 
 
-@pytest.mark.parametrize('mode,group', [('unrolled', 64), ('coop', 64), ('coop', 128)])
+@pytest.mark.parametrize('mode,group', [('auto', 64), ('unrolled', 64), ('coop', 64),
+                                        ('coop', 128)])
 def test_touch_sensors_match_oracle(mode, group):
   """mjSENS_TOUCH (hopper toe / heel): the device reading after one physics
   step against the oracle's contact forces and the same ray-in-zone rule,
   evaluated between mj_step2 and mj_step1 as mj_sensorAcc does."""
   model = helpers.load_model('hopper')
   nenv = 48
-  hm, hb = _device_batch(model, helpers.TASKS['hopper'], 'f64', nenv, mode, group=group)
+  # the fp64 unrolled one-lane build spills 369 SGPRs: `auto` ships the rolled
+  # form; the unrolled one is compared too, under the test-only override
+  with (build.allow_overbudget() if mode == 'unrolled' else contextlib.nullcontext()):
+    hm, hb = _device_batch(model, helpers.TASKS['hopper'], 'f64', nenv, mode, group=group)
   qpos, qvel = helpers.initial_states(model, 'hopper', nenv, seed=2)
   om, datas = _oracle_envs(model, qpos, qvel)
   rs = np.random.RandomState(0)
@@ -312,7 +329,23 @@ def test_fp32_cartpole_free_run_1000_steps():
   assert np.median(eq) <= 1e-4, np.median(eq)
   assert np.percentile(eq, 90) <= 1.5e-3, np.percentile(eq, 90)
   assert np.mean(eq <= 1e-4) >= 0.75, np.mean(eq <= 1e-4)
-  assert eq.max() <= 0.5, eq.max()
+  assert eq.max() <= 0.3, eq.max()
+
+
+def test_mixed_cartpole_free_run_1000_steps():
+  """The same 256 adversarial starts and torques with precision='mixed': the
+  low state words remove the state-rounding part of the fp32 error (the study
+  of DESIGN 4.3: p99 3.4e-4 -> 2.7e-5 on task-like starts), so the bulk must
+  be no worse than the fp32 build's and the same asserts hold."""
+  eq, _ = _free_run('cartpole', 'mixed', 256, 1000, 1)
+  ef, _ = _free_run('cartpole', 'f32', 256, 1000, 1)
+  print('OBSERVED cartpole mixed 1000-step free run: qpos rel err median %.2e p90 %.2e '
+        'max %.2e share<=1e-4 %.3f (fp32: %.2e %.2e %.2e %.3f)' % (
+            np.median(eq), np.percentile(eq, 90), eq.max(), np.mean(eq <= 1e-4),
+            np.median(ef), np.percentile(ef, 90), ef.max(), np.mean(ef <= 1e-4)))
+  assert np.median(eq) <= max(1.5*np.median(ef), 1e-6)
+  assert np.mean(eq <= 1e-4) >= np.mean(ef <= 1e-4) - 0.02
+  assert np.median(eq) <= 1e-4 and np.percentile(eq, 90) <= 1.5e-3
 
 
 @pytest.mark.parametrize('key,mode', [(k, 'auto') for k in sorted(kat_models.GPU_MODELS)] +
@@ -320,15 +353,26 @@ def test_fp32_cartpole_free_run_1000_steps():
 def test_known_answer_models_on_device(key, mode):
   """Box/sphere/capsule primitives and free joints through the HIP path.
 
-  The 20-dof `primitives` model is also run in both explicit build modes: its
-  fp64 UNROLLED code object computed one dof's velocity wrongly by g*h on the
-  GPU in round 1 (hidden behind the spill-aware `auto` mode).  With the current
-  sources the unrolled build agrees with the oracle to 1e-15 per step
-  (tools/gpu_primitives_unrolled.py), the host build is clean under
-  MemorySanitizer, and this test keeps it that way."""
+  The 20-dof `primitives` model is also run in both explicit build modes.  Its
+  fp64 UNROLLED code object spills ~2600 registers -- far beyond the budget
+  within which the product ships such a build (`build_model(mode='unrolled')`
+  raises; asserted below) -- and builds of this kind have twice produced a
+  wrong trajectory on the GPU after semantics-preserving source edits
+  (tools/spill_hazard/).  It is built here with the explicit
+  override as a canary: the current sources happen to be exact."""
   model = compiler.from_xml_string(kat_models.GPU_MODELS[key])
   nenv = 32
-  hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv, mode)
+  if (key, mode) == ('primitives', 'unrolled'):
+    cached = build.build_model       # the product path refuses this build
+    import contextlib
+import os
+    assert os.environ.get('DMC_ALLOW_OVERBUDGET') != '1'
+    with pytest.raises(RuntimeError, match='spills'):
+      cached(model, codegen.TASK_NONE, 'f64', mode='unrolled')
+    with build.allow_overbudget():
+      hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv, mode)
+  else:
+    hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv, mode)
   rs = np.random.RandomState(2)
   qpos = np.tile(model.qpos0, (nenv, 1))
   qvel = 0.2*rs.randn(nenv, model.nv)
@@ -653,6 +697,41 @@ def test_checkpoint_round_trip_continues_bit_for_bit(tmp_path):
     wide.physics.load_checkpoint(path)              # precision mismatch
   for e in (env, other, small, wide):
     e.physics.free()
+
+
+def test_checkpoint_of_a_mixed_precision_batch_and_old_format_files(tmp_path):
+  """precision='mixed': the checkpoint holds the fp32 words of the state, the
+  low words restart at zero, so the restored batch starts from the same fp32
+  state and continues to fp32 rounding (documented in save_checkpoint).  A file
+  without the newer fields is refused with a message naming them."""
+  def make():
+    return suite.load('cartpole', 'swingup', task_kwargs={'random': 5},
+                      environment_kwargs={'batch_size': 64, 'precision': 'mixed'})
+  env = make()
+  env.reset()
+  rs = np.random.RandomState(1)
+  acts = rs.uniform(-1, 1, (40, 64, 1))
+  for a in acts[:20]:
+    env.step(a)
+  path = str(tmp_path/'mixed.npz')
+  env.physics.save_checkpoint(path, step_count=env.step_count)
+  q_saved = np.asarray(env.physics.data.qpos).copy()
+  other = make()
+  other.reset()
+  assert other.physics.load_checkpoint(path) == 20
+  np.testing.assert_array_equal(np.asarray(other.physics.data.qpos), q_saved)
+  for a in acts[20:]:
+    ts, ts2 = env.step(a), other.step(a)
+  for k in ts.observation:
+    np.testing.assert_allclose(ts.observation[k], ts2.observation[k], atol=2e-5)
+  with np.load(path) as z:
+    old = {k: z[k] for k in ('model_hash', 'precision', 'step_count', 'qpos',
+                             'qvel', 'qacc_warmstart', 'time')}
+  np.savez(str(tmp_path/'old.npz'), **old)
+  with pytest.raises(ValueError, match='lacks ctrl'):
+    other.physics.load_checkpoint(str(tmp_path/'old.npz'))
+  env.physics.free()
+  other.physics.free()
 
 
 @pytest.mark.parametrize('domain,task', [('reacher', 'hard'), ('point_mass', 'hard')])
@@ -1064,6 +1143,12 @@ def test_north_star_1000_step_free_run(name):
     hb.free()
 
 
+# control steps after which the fp32 several-lanes free run is still compared
+# with a bound, and (median, max) asserted there
+EARLY = {'humanoid': 10, 'walker': 10, 'hopper': 25}
+FP32_EARLY = {'humanoid': (1e-3, 1e-1), 'walker': (1e-3, 1e-1), 'hopper': (1e-3, 1e-1)}
+
+
 @pytest.mark.parametrize('name,nsub,steps', [('humanoid', 5, 60), ('walker', 10, 100),
                                              ('hopper', 4, 150)])
 def test_free_run_trajectories_several_lanes_kernel(name, nsub, steps):
@@ -1088,12 +1173,15 @@ def test_free_run_trajectories_several_lanes_kernel(name, nsub, steps):
   ctrls = rs.uniform(-1, 1, (steps, nenv, model.nu))
   om, datas = _oracle_envs(model, qpos, qvel)
   contacts = 0
+  mid = None
   for t in range(steps):
     for i, d in enumerate(datas):
       d.ctrl[:] = ctrls[t, i]
       for _ in range(nsub):
         d.physics_step()
       contacts += d.ncon > 0
+    if t + 1 == EARLY[name]:
+      mid = np.array([d.qpos.copy() for d in datas])
   assert contacts > steps*nenv//4           # the floor was involved
   ref = np.array([d.qpos.copy() for d in datas])
   for precision in ('f64', 'f32'):
@@ -1101,20 +1189,30 @@ def test_free_run_trajectories_several_lanes_kernel(name, nsub, steps):
     hm, hb = _device_batch(model, helpers.TASKS[name], precision, nenv, 'coop',
                            group=128)
     hb.set_state(qpos.T, qvel.T)
+    early = None
     for t in range(steps):
       hb.step_host(ctrls[t], nsub)
+      if t + 1 == EARLY[name]:
+        early = helpers.rel_err(hb.read(W.FIELD_QPOS).T.astype(np.float64), mid)
     e = helpers.rel_err(hb.read(W.FIELD_QPOS).T.astype(np.float64), ref)
-    print('OBSERVED %s %s %d-step free run (several lanes per env): median %.2e max %.2e'
-          % (name, precision, steps, np.median(e), e.max()))
+    print('OBSERVED %s %s free run (several lanes per env): after %d control steps '
+          'median %.2e max %.2e; after %d median %.2e max %.2e'
+          % (name, precision, EARLY[name], np.median(early), early.max(),
+             steps, np.median(e), e.max()))
     assert not hb.read(W.FIELD_WARN).any()
     if precision == 'f64':
       assert e.max() <= 1e-5, e.max()
     else:
       # falling, contact-rich bodies under random torques are chaotic: fp32
       # rounding (per-step error ~1e-6) grows by orders of magnitude per hundred
-      # physics steps.  Observed medians after these horizons: humanoid 3.5e-3,
-      # hopper 4.2e-3, walker (1000 physics steps) 0.13 -- decorrelated; the
-      # bound is ~10x that where it still means something.
+      # physics steps.  What fp32 can be held to is the early part of the run
+      # (bounds ~10x the values observed on MI355X, round 3) ...
+      med, top = FP32_EARLY[name]
+      assert np.median(early) <= med, np.median(early)
+      assert early.max() <= top, early.max()
+      # ... and, at the full horizon, finiteness plus the median where it still
+      # means something (observed: humanoid 3.5e-3, hopper 4.2e-3; the walker
+      # has decorrelated by then: 0.13)
       assert np.isfinite(e).all()
       limit = {'humanoid': 4e-2, 'hopper': 5e-2}.get(name)
       if limit is not None:

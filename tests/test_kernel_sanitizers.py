@@ -26,15 +26,19 @@ SHIM = os.path.join(ROOT, 'tests', 'host_shim')
 KERNEL = os.path.join(ROOT, 'dm_control_amd', 'csrc', 'dmc_kernels.hip')
 
 
-def _build(model, task, tmp_path, unroll, extra=()):
+def _build(model, task, tmp_path, unroll, extra=(), sanitize=True, f64=True,
+           name='harness'):
   header = tmp_path/'model.h'
   text = codegen.generate_header(model, task, unroll=unroll)
   header.write_text(text.replace('static __device__ constexpr',
                                  'static constexpr'))
-  exe = tmp_path/'harness'
-  cmd = ['g++', '-std=c++17', '-O1', '-g', '-fsanitize=address,undefined',
-         '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer',
-         '-DDMC_REAL_IS_DOUBLE', '-DDMC_LDS_BUDGET=16384'] + list(extra) + [
+  exe = tmp_path/name
+  mode = (['-O1', '-g', '-fsanitize=address,undefined',
+           '-fno-sanitize-recover=undefined', '-fno-omit-frame-pointer']
+          if sanitize else ['-O2', '-ffp-contract=off'])
+  cmd = ['g++', '-std=c++17', '-w'] + mode + (
+      ['-DDMC_REAL_IS_DOUBLE'] if f64 else []) + [
+         '-DDMC_LDS_BUDGET=16384'] + list(extra) + [
          '-DDMC_MODEL_HEADER="%s"' % header,
          '-DDMC_KERNEL_SOURCE="%s"' % KERNEL,
          '-I', os.path.join(ROOT, 'dm_control_amd', 'csrc'), '-I', SHIM,
@@ -62,7 +66,12 @@ def _run(exe, steps, qpos, qvel):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize('name,unroll,extra', [
     ('cheetah', True, ()), ('cheetah', False, ()), ('primitives', True, ()),
-    ('hopper', True, ())])                           # touch sensors
+    ('hopper', True, ()),                            # touch sensors
+    # precision='mixed' (DMC_STATE_COMP): the (high, low) state words and their
+    # workspace tier under ASan; with real = double the low words are zero and
+    # the trajectory must still be the oracle's
+    ('cheetah', True, ('-DDMC_STATE_COMP=1',)),
+    ('cartpole', True, ('-DDMC_STATE_COMP=1',))])
 def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path):
   if name == 'primitives':
     model, task = compiler.from_xml_string(kat_models.PRIMITIVES), 0
@@ -88,7 +97,43 @@ def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path
     assert warn == 0
     np.testing.assert_allclose(state[:model.nq], d.qpos, rtol=0, atol=1e-9)
     np.testing.assert_allclose(state[model.nq:], d.qvel, rtol=0, atol=1e-8)
-  assert touched      # constraint rows (LDS and HBM tiers) were exercised
+  # constraint rows (LDS and HBM tiers) were exercised (the cart-pole: RK4 path)
+  assert touched or name == 'cartpole'
+
+
+@pytest.mark.timeout(900)
+def test_mixed_precision_source_beats_plain_fp32_on_the_smooth_system(tmp_path):
+  """precision='mixed' = fp32 arithmetic with qpos/qvel carried between steps
+  as fp64 (high, low) pairs (DMC_STATE_COMP).  The kernel source is built for
+  the host in fp32 with and without it and run free for 1000 steps of the
+  cart-pole next to the fp64 oracle: the compensated state must stay closer
+  (state rounding is what the tail of the fp32 build is made of)
+  and within BASELINE's 1e-4."""
+  model, task = helpers.load_model('cartpole'), helpers.TASKS['cartpole']
+  q, v = helpers.initial_states(model, 'cartpole', 8, seed=3)
+  exes = {tag: _build(model, task, tmp_path, True, extra, sanitize=False,
+                      f64=False, name=tag)
+          for tag, extra in (('f32', ()), ('mixed', ('-DDMC_STATE_COMP=1',)))}
+  om = oracle.OracleModel(model)
+  worse = 0
+  for e in range(4):
+    d = oracle.OracleData(om)
+    d.qpos[:] = q[e]
+    d.qvel[:] = v[e]
+    d.step1()
+    ref = []
+    for _ in range(1000):
+      d.physics_step()
+      ref.append(d.qpos.copy())
+    ref = np.array(ref)
+    err = {}
+    for tag, exe in exes.items():
+      st = np.array([r[0][:model.nq] for r in _run(exe, 1000, q[e], v[e])])
+      err[tag] = np.abs(st - ref).max(axis=1)/np.maximum(1, np.abs(ref).max(axis=1))
+    assert err['mixed'][-1] <= 1e-4
+    assert err['mixed'][:100].max() <= 1e-6
+    worse += err['mixed'][-1] > err['f32'][-1]
+  assert worse <= 1       # rounding is not monotone env by env; the rule is
 
 
 # ---------------------------------------------------------------------------

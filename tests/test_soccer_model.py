@@ -185,7 +185,8 @@ def test_walker_scene_on_device_matches_oracle():
   from dm_control_amd import build, wrapper as W
   m = _walker_model()
   rs = np.random.RandomState(0)
-  hm = W.HipModel(build.build_model(m, 0, 'f64', mode='coop', ncon_max=4))
+  with build.allow_overbudget():   # 62 dofs on one lane group: thousands of spills
+    hm = W.HipModel(build.build_model(m, 0, 'f64', mode='coop', ncon_max=4))
   hb = W.HipBatch(hm, 16)
   qpos, qvel = _states(m, 16, rs, height=1.6)
   qpos[8:, 2] = 1.13                          # toes at the floor
@@ -194,7 +195,8 @@ def test_walker_scene_on_device_matches_oracle():
   assert not hb.read(W.FIELD_WARN).any()
   assert e.max() <= 1e-9, e.max()
   hb.free()
-  hm = W.HipModel(build.build_model(m, 0, 'f32', mode='coop'))
+  with build.allow_overbudget():
+    hm = W.HipModel(build.build_model(m, 0, 'f32', mode='coop'))
   hb = W.HipBatch(hm, 32)
   qpos, qvel = _states(m, 32, rs, height=1.05)
   qpos[16:, 2] = 0.25                         # lying / crouching in the floor
