@@ -228,6 +228,33 @@ def capacities(m, pairs, ncon_max=None):
   return max(ncon_max, 1), max(nefc_max, 1)
 
 
+def planar_in_xz(m):
+  """True if every dof moves its bodies inside the x-z plane: slides along an
+  axis with no y component and hinges about +-y, on bodies whose frames are
+  rotations about y only.  Then the Jacobian of any point along the world y
+  direction is exactly zero, so a contact whose frame has a tangent along +-y
+  gets two IDENTICAL pyramid rows J_n +- mu*0: the one-env-per-lane kernel
+  stores them as one row of twice the weight (DMC_PLANAR_MERGE)."""
+  import numpy as np
+  if m.nv == 0:
+    return False
+  for j in range(m.njnt):
+    axis = np.asarray(m.jnt_axis[j], float)
+    if m.jnt_type[j] == mdl.JNT_SLIDE:
+      if axis[1] != 0.0:
+        return False
+    elif m.jnt_type[j] == mdl.JNT_HINGE:
+      if axis[0] != 0.0 or axis[2] != 0.0:
+        return False
+    else:
+      return False
+  for b in range(1, m.nbody):
+    quat = m.body_quat[b]      # (the inertial frame does not enter a Jacobian)
+    if float(quat[1]) != 0.0 or float(quat[3]) != 0.0:   # (w, x, y, z): about y only
+      return False
+  return True
+
+
 def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   """Returns the text of the constants header for model `m`."""
   if m.opt.cone != mdl.CONE_PYRAMIDAL:
@@ -311,6 +338,7 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   ci('ITERATIONS', m.opt.iterations)
   ci('NPAIR', len(pairs)); ci('NCON_MAX', ncon_max); ci('NEFC_MAX', nefc_max)
   ci('NLIMIT', len(limit_jnt)); ci('TASK', task)
+  ci('PLANAR_XZ', 1 if planar_in_xz(m) else 0)
   ci('NOBS', observation_size(m, task))
   ci('NTASKDATA', task_data_size(task))
   tr('task_data_default', task_data_default(m, task) or [0])

@@ -322,6 +322,7 @@ struct Env {
   real prof[8];
 #endif
   int ncon, nefc, nefc_limit, iters;
+  int nmerged;     // pyramid edge pairs stored as one row (PLANAR_MERGE)
   unsigned warn;
 };
 
@@ -1182,6 +1183,14 @@ DEV void detect_contacts(Env& E, const Work& W) {
 // tables through vector loads, and the body chains are applied as dof bit
 // masks over the statically indexed cdof registers (no dynamic indexing of
 // per-lane state).
+// pyramid edge pairs of planar models stored as one row: word 10 of a contact
+// record then carries pair + MERGE_STRIDE * (merged pairs of this contact)
+constexpr int MERGE_STRIDE = 4096;
+#ifndef DMC_NO_PLANAR_MERGE
+constexpr bool PLANAR_MERGE = PLANAR_XZ != 0 && NPAIR < MERGE_STRIDE;
+#else
+constexpr bool PLANAR_MERGE = false;     // ablation builds (tools/gpu_ablate.py)
+#endif
 template <class Rec>
 DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
   const int p = (int)rec.get(10);
@@ -1239,10 +1248,19 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
   real R0 = (1 - imp)*pair_diag[6*p + 1]/imp;
   if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
   const real Rpy = 2*mu0*mu0*R0;
+  int merged = 0;
   DMC_UNROLL
   for (int k = 1; k < 3; k++) {
     const real mu = pair_friction[5*p + k - 1];
     real row[NVX];
+    // A model that moves inside the x-z plane (codegen.planar_in_xz) has a zero
+    // Jacobian along world y, so for a tangent that is exactly +-y the two
+    // pyramid edges J_n +- mu*0 are the same row: one row of twice the weight
+    // (D = 2/R) has the same cost, force and Hessian term as the pair.
+    if (PLANAR_MERGE && f[3*k] == 0 && f[3*k + 2] == 0) {
+      if (push_row(E, W, jb[0], pm, K, B, imp, Rpy*R(0.5))) { merged++; E.nmerged++; }
+      continue;
+    }
     DMC_UNROLL
     for (int j = 0; j < NV; j++) row[j] = jb[0][j] + mu*jb[k][j];
     push_row(E, W, row, pm, K, B, imp, Rpy);
@@ -1272,6 +1290,8 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
       push_row(E, W, row, pm, K, B, imp, Rpy);
     }
   }
+  // the touch sensors walk the rows contact by contact: note how many this one has
+  if (PLANAR_MERGE && merged) rec.set(10, (real)(p + MERGE_STRIDE*merged));
 }
 
 DEV void contact_rows(Env& E, const Work& W) {
@@ -1549,9 +1569,10 @@ DEV real touch_hit(const EnvT& E, int s, const real* pos, const real* normal,
 }
 template <class Rec>
 DEV void touch_of_contact(Env& E, const Work& W, const Rec& rec, int& r) {
-  const int p = (int)rec.get(10);
+  const int word = (int)rec.get(10);
+  const int p = PLANAR_MERGE ? word % MERGE_STRIDE : word;
   if (rec.get(9) >= pair_includemargin[p]) return;   // contact without rows
-  const int nrow = pair_nrow[p];
+  const int nrow = pair_nrow[p] - (PLANAR_MERGE ? word/MERGE_STRIDE : 0);
   real fn = 0;
   for (int j = 0; j < nrow; j++)
     if (r + j < E.nefc) fn += row_force(W, r + j);
@@ -1583,7 +1604,7 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
   crb_factor(E, W);
   com_vel(E);
   smooth_forces(E, W, actuation);
-  E.ncon = 0; E.nefc = 0; E.iters = 0;
+  E.ncon = 0; E.nefc = 0; E.iters = 0; E.nmerged = 0;
   limit_rows(E, W);
   E.nefc_limit = E.nefc;
 #ifndef DMC_ABLATE_CONTACT
@@ -2108,7 +2129,7 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
 #ifdef DMC_SOLVER_PROFILE
   for (int k = 0; k < 8; k++) E.prof[k] = 0;
 #endif
-  E.warn = 0; E.ncon = 0; E.nefc = 0; E.nefc_limit = 0; E.iters = 0;
+  E.warn = 0; E.ncon = 0; E.nefc = 0; E.nefc_limit = 0; E.iters = 0; E.nmerged = 0;
   DMC_UNROLL
   for (int s = 0; s < (NTOUCH > 0 ? NTOUCH : 1); s++) E.touch[s] = 0;
 }
@@ -2188,7 +2209,8 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
     DMC_UNROLL
     for (int i = 0; i < NBODY*9; i++) a.xmat[i*n + e] = E.xmat[i];
   }
-  a.stats[e] = E.ncon; a.stats[n + e] = E.nefc; a.stats[2*n + e] = E.iters;
+  // nefc as mj_makeConstraint counts it: a merged edge pair is two rows there
+  a.stats[e] = E.ncon; a.stats[n + e] = E.nefc + E.nmerged; a.stats[2*n + e] = E.iters;
 }
 
 // nsub x Physics.step, then observation + reward of the new state.
@@ -2270,7 +2292,7 @@ dmc_observe(DmcArgs a) {
   if (NTOUCH > 0) {
     E.ncon = ncon_forward; E.nefc = nefc_forward;
   } else if (a.flags & 4) {   // count contacts (humanoid reset rejection test)
-    E.ncon = 0; E.nefc = 0;
+    E.ncon = 0; E.nefc = 0; E.nmerged = 0;
     if (NPAIR > 0) detect_contacts(E, W);
   }
   store_outputs(E, a, e, false, lds_rows);

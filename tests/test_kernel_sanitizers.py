@@ -93,6 +93,9 @@ def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path
   touched = False
   for state, (ncon, nefc, iters, warn) in rows:
     touched |= d.nefc > 0
+    # contact and row counts as mj_makeConstraint counts them (a pyramid edge
+    # pair that the planar models store as one row still counts as two)
+    assert (ncon, nefc) == (d.ncon, d.nefc)
     d.physics_step()
     assert warn == 0
     np.testing.assert_allclose(state[:model.nq], d.qpos, rtol=0, atol=1e-9)

@@ -12,14 +12,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import helpers
 from dm_control_amd import build, wrapper as W
 name = sys.argv[1]
-batches = [int(x) for x in sys.argv[2:]] or [256, 1024, 2048, 4096, 8192]
+BUILD_ONLY = '--build-only' in sys.argv      # pre-build here, run on the GPU box
+batches = [int(x) for x in sys.argv[2:] if not x.startswith('--')] or [256, 1024, 2048, 4096, 8192]
 model = helpers.load_model(name)
 nsub = {'cheetah': 1, 'walker': 10, 'hopper': 4, 'humanoid': 5}[name]
 PREC = os.environ.get('DMC_SWEEP_PRECISION', 'f32')
 VARIANTS = (('one env per lane', 'auto', 64, ()),
             ('64 lanes x 2 waves', 'coop', 128, ()),
             ('64 lanes', 'coop', 64, ()),
-            ('32 lanes', 'coop', 32, ()))
+            ('32 lanes', 'coop', 32, ()),
+            ('16 lanes', 'coop', 16, ()),
+            ('8 lanes', 'coop', 8, ()))
 for B in batches:
   line = '%s %s B=%d:' % (name, PREC, B)
   for label, mode, group, flags in VARIANTS:
@@ -28,8 +31,10 @@ for B in batches:
     try:
       path = build.build_model(model, helpers.TASKS[name], PREC, mode=mode, group=group,
                                extra_flags=flags)
-    except Exception as e:   # LDS does not fit
-      line += '  %s n/a' % label; continue
+    except Exception as e:   # LDS does not fit / beyond the spill budget
+      line += '  | %s n/a' % label; continue
+    if BUILD_ONLY:
+      line += '  | %s built' % label; continue
     hm = W.HipModel(path); hb = W.HipBatch(hm, B)
     qpos, qvel = helpers.initial_states(model, name, B, seed=1)
     hb.set_state(qpos.T, qvel.T)

@@ -30,7 +30,10 @@ VARIANTS = [
     ('select', SEL),
     ('select + waitcnt-forcezero', SEL + ('-mllvm', '-amdgpu-waitcnt-forcezero')),
     ('select + snop-padding=1', SEL + ('-mllvm', '-amdgpu-snop-padding=1')),
-    ('select + spill-sgpr-to-vgpr=0', SEL + ('-mllvm', '-amdgpu-spill-sgpr-to-vgpr=0')),
+    # built but NOT run: with SGPR spills sent to memory this kernel raised a GPU
+    # memory access fault (gpurun_out/r03a, round 3) -- never launch it again
+    ('select + spill-sgpr-to-vgpr=0 [FAULTS: build only]',
+     SEL + ('-mllvm', '-amdgpu-spill-sgpr-to-vgpr=0')),
     ('select + prealloc-sgpr-spill-vgprs', SEL + ('-mllvm', '-amdgpu-prealloc-sgpr-spill-vgprs')),
     ('select + spill-vgpr-to-agpr=0', SEL + ('-mllvm', '-amdgpu-spill-vgpr-to-agpr=0')),
     ('select + disable-ssc', SEL + ('-mllvm', '-disable-ssc')),
@@ -73,7 +76,14 @@ def main():
     ref.append(d.qacc.copy())
   ref = np.array(ref)
   print('oracle qacc[18:20] env0 %r' % ref[0, 18:].tolist())
+  dump = {'qpos': qpos, 'qvel': qvel, 'oracle_qacc': ref,
+          'oracle_qM': np.array([d.qM.copy() for d in datas]) if hasattr(datas[0], 'qM') else 0,
+          'oracle_qfrc_smooth': np.array([np.asarray(d.qfrc_smooth).copy() for d in datas])
+          if hasattr(datas[0], 'qfrc_smooth') else 0}
+  only = sys.argv[2:]          # optional: substrings of the variants to run
   for name, p in paths:
+    if 'FAULTS' in name or (only and not any(o in name for o in only)):
+      continue
     hm = W.HipModel(p)
     hb = W.HipBatch(hm, nenv)
     hb.set_aux_outputs(True)
@@ -84,7 +94,11 @@ def main():
     print('%-40s max|dqacc| dofs<18 %.1e  dof18 %.3e  dof19 %.3e  device qacc[18:20] env0 %r ratio18 %r'
           % (name, err[:18].max(), err[18], err[19], acc[0, 18:].tolist(),
              (acc[:, 18]/ref[:, 18]).tolist()[:3]), flush=True)
+    dump['qacc ' + name] = acc.copy()
     hb.free(); hm.free()
+  out = os.path.join(ROOT, 'gpurun_out', 'spill_hazard_dump.npz')
+  os.makedirs(os.path.dirname(out), exist_ok=True)
+  np.savez(out, **dump)
 
 
 if __name__ == '__main__':
