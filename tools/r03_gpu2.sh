@@ -20,7 +20,7 @@ for n in cheetah walker hopper; do
   DMC_SWEEP_PRECISION=f64 timeout -k 10 300 python tools/gpu_group_sweep.py $n 1024 4096 8192 32768 >> $O/f64_shape_sweep.txt 2>&1 || exit 1
 done
 cat $O/f64_shape_sweep.txt | grep -v amdgpu.ids
-timeout -k 10 300 python tools/spill_hazard/variants.py run ifchain "select" > $O/spill_hazard_safe.txt 2>&1 || { tail -5 $O/spill_hazard_safe.txt; exit 1; }
+timeout -k 10 300 python tools/spill_hazard/variants.py run ifchain "=select" forcezero snop > $O/spill_hazard_safe.txt 2>&1 || { tail -5 $O/spill_hazard_safe.txt; exit 1; }
 cut -c1-330 $O/spill_hazard_safe.txt | grep -v amdgpu.ids
 cp gpurun_out/spill_hazard_dump.npz $O/spill_hazard_dump_safe.npz
 for v in prealloc disable-ssc dce-in-ra opt-exec-mask rewrite-partial vgpr-to-agpr; do

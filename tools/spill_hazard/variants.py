@@ -82,7 +82,8 @@ def main():
           if hasattr(datas[0], 'qfrc_smooth') else 0}
   only = sys.argv[2:]          # optional: substrings of the variants to run
   for name, p in paths:
-    if 'FAULTS' in name or (only and not any(o in name for o in only)):
+    if 'FAULTS' in name or (only and not any(
+        name == o[1:] if o.startswith('=') else o in name for o in only)):
       continue
     hm = W.HipModel(p)
     hb = W.HipBatch(hm, nenv)
