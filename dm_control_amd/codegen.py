@@ -450,17 +450,18 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
     for d in c:
       bits |= 1 << d
     masks.append(bits)
-  if m.nv > 64:
-    raise UnsupportedModelError('nv > 64 is not supported')
   roots = sorted(set(int(r) for r in m.body_rootid[1:])) or [0]
   ci('NROOT', len(roots))
   ti('root_body', roots)
   ti('body_rootidx', [roots.index(int(r)) if int(r) in roots else 0
                       for r in m.body_rootid])
-  w('static __device__ constexpr unsigned body_dofmask_lo[] = {%s};'
-    % ', '.join('%du' % (b & 0xffffffff) for b in masks))
-  w('static __device__ constexpr unsigned body_dofmask_hi[] = {%s};'
-    % ', '.join('%du' % (b >> 32) for b in masks))
+  # [body][word]: bit (j & 31) of word (j >> 5) set <=> dof j moves the body
+  # (multi-word, so scenes with several walkers -- nv > 64 -- compile too)
+  nmaskw = max(1, (m.nv + 31)//32)
+  ci('NMASKW', nmaskw)
+  w('static __device__ constexpr unsigned body_dofmask[] = {%s};'
+    % ', '.join('%du' % ((b >> (32*k)) & 0xffffffff)
+                for b in masks for k in range(nmaskw)))
   ti('pair_b1', [int(m.geom_bodyid[p[0]]) for p in pairs])
   ti('pair_b2', [int(m.geom_bodyid[p[1]]) for p in pairs])
   ci('MAXCHAIN', maxchain)

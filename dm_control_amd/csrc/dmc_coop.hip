@@ -1123,8 +1123,8 @@ struct Coop {
       for (int k = 0; k < 3; k++) { pos[k] = rec[k]; fin[k] = rec[3 + k]; fin[3 + k] = rec[6 + k]; }
       make_frame(fin, f);
       const int b1 = pair_b1[p], b2 = pair_b2[p], dim = pair_dim[p];
-      const unsigned m1 = j < 32 ? body_dofmask_lo[b1] >> j : body_dofmask_hi[b1] >> (j - 32);
-      const unsigned m2 = j < 32 ? body_dofmask_lo[b2] >> j : body_dofmask_hi[b2] >> (j - 32);
+      const unsigned m1 = body_dofmask[NMASKW*b1 + (j >> 5)] >> (j & 31);
+      const unsigned m2 = body_dofmask[NMASKW*b2 + (j >> 5)] >> (j & 31);
       const bool in1 = (m1 & 1u) != 0, in2 = (m2 & 1u) != 0;
       real off1[3], off2[3];
       for (int k = 0; k < 3; k++) {

@@ -1203,8 +1203,12 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
   make_frame(fin, f);
   const int b1 = pair_b1[p], b2 = pair_b2[p];
   const int dim = pair_dim[p];
-  const unsigned m1lo = body_dofmask_lo[b1], m2lo = body_dofmask_lo[b2];
-  const unsigned m1hi = body_dofmask_hi[b1], m2hi = body_dofmask_hi[b2];
+  unsigned m1[NMASKW], m2[NMASKW];     // which dofs move body 1 / body 2
+  DMC_UNROLL
+  for (int k = 0; k < NMASKW; k++) {
+    m1[k] = body_dofmask[NMASKW*b1 + k];
+    m2[k] = body_dofmask[NMASKW*b2 + k];
+  }
   // offsets of the contact point from the subtree-root CoM of each body
   real off1[3] = {0, 0, 0}, off2[3] = {0, 0, 0};
   const int r1 = body_rootidx[b1], r2 = body_rootidx[b2];
@@ -1230,8 +1234,8 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
     cross3(w2, off2, dir);
     DMC_UNROLL
     for (int j = 0; j < NV; j++) {
-      const bool in1 = ((j < 32 ? m1lo >> j : m1hi >> (j - 32)) & 1u) != 0;
-      const bool in2 = ((j < 32 ? m2lo >> j : m2hi >> (j - 32)) & 1u) != 0;
+      const bool in1 = ((m1[j >> 5] >> (j & 31)) & 1u) != 0;
+      const bool in2 = ((m2[j >> 5] >> (j & 31)) & 1u) != 0;
       const real* cd = E.cdof + 6*j;
       const real dl = dot3(dir, cd + 3);
       const real v2 = dl + dot3(w2, cd), v1 = dl + dot3(w1, cd);
@@ -1277,8 +1281,8 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
       real jt[NVX], row[NVX];
       DMC_UNROLL
       for (int j = 0; j < NV; j++) {
-        const bool in1 = ((j < 32 ? m1lo >> j : m1hi >> (j - 32)) & 1u) != 0;
-        const bool in2 = ((j < 32 ? m2lo >> j : m2hi >> (j - 32)) & 1u) != 0;
+        const bool in1 = ((m1[j >> 5] >> (j & 31)) & 1u) != 0;
+        const bool in2 = ((m2[j >> 5] >> (j & 31)) & 1u) != 0;
         const real v = dot3(dir, E.cdof + 6*j);
         jt[j] = (in2 ? v : R(0)) - (in1 ? v : R(0));
       }

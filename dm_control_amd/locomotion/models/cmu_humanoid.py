@@ -39,7 +39,7 @@ def add_defaults(root):
 
 
 def add_walker(root, world, actuator, contact, prefix='', pos=(0, 0, 1.0),
-               quat=(0.7071067811865476, 0.7071067811865476, 0, 0)):
+               quat=(0.7071067811865476, 0.7071067811865476, 0, 0), contype=None):
   """Adds one walker under `world`; names get `prefix`.  `quat`: the CMU model's
   up axis is +y, the default orientation stands it up along +z."""
   nodes = {}
@@ -56,8 +56,10 @@ def add_walker(root, world, actuator, contact, prefix='', pos=(0, 0, 1.0),
   for name, body, kind, size, gpos, gquat in T.GEOMS:
     if kind == 'ellipsoid':     # equal-volume sphere, see the module docstring
       kind, size = 'sphere', ((size[0]*size[1]*size[2])**(1.0/3.0),)
+    extra = {} if contype is None else {'contype': contype}
     m.node(nodes[body], 'geom', name=prefix + name, type=kind,
-           size=tuple(s for s in size if s != 0) or size[:1], pos=gpos, quat=gquat)
+           size=tuple(s for s in size if s != 0) or size[:1], pos=gpos, quat=gquat,
+           **extra)
   for name, forcerange, kp in T.POSITION_ACTUATORS:
     lo, hi = ranges[name]
     slope = (hi - lo)/2.0

@@ -22,13 +22,27 @@ BALL = dict(radius=0.35, mass=0.045, friction=(0.7, 0.075, 0.075), damp_ratio=1.
 PITCH_SIZE = (9.0, 6.0)            # half extents of the fixed arena (m)
 
 
+def default_positions(num_walkers):
+  """Where `build` puts the walkers: two rows facing each other across x = 0."""
+  return [((-1 if i % 2 == 0 else 1)*(1.5 + i//2), 0.6*(i//2), 1.05)
+          for i in range(num_walkers)]
+
+
 def build(num_walkers=1, with_ball=True, pitch_size=PITCH_SIZE,
-          nconmax_per_player=200, njmax_per_player=200):
+          nconmax_per_player=200, njmax_per_player=200,
+          walker_positions=None, disable_walker_contacts=False):
   """MJCF string of the scene.  Walkers stand in a row facing the ball.
 
-  (Oracle and kernels address the dofs of a kinematic chain with 64-bit masks,
-  i.e. nv <= 64: one walker (62 dofs) OR ball + nothing else can be stepped
-  today; several walkers on one pitch are the next stage.)"""
+  walker_positions: root positions, default `default_positions(num_walkers)`.
+  disable_walker_contacts: the reference's option of the same name
+  (soccer/task.py:29-33, 84-85): `contype=0` on every walker geom, so walkers
+  touch the pitch and the ball (whose contype matches the walkers'
+  conaffinity) but neither each other nor themselves.
+
+  A 2v2 scene is nq 259, nv 254, nu 224: it compiles, generates
+  a kernel header (dof sets are multi-word) and steps on the CPU oracle; the
+  device kernels hold one scene's dense M / Hessian per lane or per lane
+  group and do not fit a scene of that size yet."""
   root = m.node(None, 'mujoco', model='soccer_%d' % num_walkers)
   m.node(root, 'option', timestep=PHYSICS_TIMESTEP)
   m.node(root, 'size', nconmax=nconmax_per_player*max(1, num_walkers),
@@ -54,8 +68,10 @@ def build(num_walkers=1, with_ball=True, pitch_size=PITCH_SIZE,
     m.node(ball, 'geom', name='ball', type='sphere', size=(BALL['radius'],), condim=6,
            priority=1, mass=BALL['mass'], friction=BALL['friction'],
            solref=(0.02, BALL['damp_ratio']), solimp=(0.9, 0.95, 0.001))
+  if walker_positions is None:
+    walker_positions = default_positions(num_walkers)
   for i in range(num_walkers):
-    side = -1 if i % 2 == 0 else 1
     cmu_humanoid.add_walker(root, world, actuator, contact, prefix='walker%d/' % i,
-                            pos=(side*(1.5 + i//2), 0.6*(i//2), 1.05))
+                            pos=tuple(walker_positions[i]),
+                            contype=0 if disable_walker_contacts else None)
   return m.to_string(root)

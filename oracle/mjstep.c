@@ -952,7 +952,7 @@ static void mjo_make_constraint(const mjoModel* m, mjoData* d) {
     int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
     int dim = c->dim, nrot = dim > 3 ? dim - 3 : 0;
     double tran, rot;
-    double jc[6*64]; /* contact-frame rows; nv <= 64 asserted at creation */
+    double* jc = d->scratch + 12*nv; /* 6*nv contact-frame rows (scratch holds 2 nv^2 + 16 nv) */
     if (c->dist >= c->includemargin) continue; /* inside margin-gap band only */
     mjo_jac(m, d, jac, jac + 3*nv, c->pos, b2);
     mjo_jac(m, d, jac1, jac1 + 3*nv, c->pos, b1);

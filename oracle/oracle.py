@@ -104,8 +104,6 @@ class OracleModel:
             a.size)
       if rc != 0:
         raise RuntimeError('oracle rejected model field %r' % name)
-    if model.nv > 64:
-      raise ValueError('oracle supports nv <= 64')
 
   def set_int(self, name, value):
     if self.lib.mjo_model_set_int(self.ptr, name.encode(), int(value)) != 0:

@@ -5,9 +5,10 @@ CMU humanoid on a fixed pitch, and the regulation ball -- against the reference
 data where the tree is present (parameter tables vs humanoid_CMU_V2019.xml),
 against closed forms (position actuators, weight on the floor, condim-6 /
 priority contact of the ball), and on the device against the oracle
-(`-m gpu`).  Composer, observables, mocap initialiser and per-episode
-recompilation are not built; several walkers on one pitch need chains beyond
-the 64-dof masks of oracle and kernels (next stage).
+(`-m gpu`).  Stage 2 groundwork: scenes with several walkers (nv > 64) compile, generate a
+kernel header (multi-word dof sets) and step on the oracle; the checks below
+are CPU-side.  Composer, observables, mocap initialiser and per-episode
+recompilation are not built.
 """
 
 import os
@@ -135,6 +136,72 @@ def test_ball_contact_is_condim_six_with_its_own_friction():
 # ---------------------------------------------------------------------------
 # device (fp64 for the tight comparison, fp32 at full contact capacity)
 # ---------------------------------------------------------------------------
+def test_two_by_two_scene_sizes_and_header():
+  """BASELINE configs[4] sizes: nq 259, nv 254, nu 224; capacities
+  as soccer/task.py:105-108; `disable_walker_contacts` (task.py:29-33) leaves
+  walker-pitch and walker-ball pairs only; the generated header carries dof sets
+  of eight 32-bit words per body."""
+  xml = soccer.build(4)
+  assert 'nconmax="800"' in xml and 'njmax="800"' in xml
+  m = compiler.from_xml_string(xml)
+  assert (m.nq, m.nv, m.nu, m.nbody) == (259, 254, 224, 130)
+  allpairs = codegen.collision_pairs(m)
+  quiet = compiler.from_xml_string(soccer.build(4, disable_walker_contacts=True))
+  pairs = codegen.collision_pairs(quiet)
+  assert len(pairs) < len(allpairs)/10
+  ball = quiet.names['geom'].index('ball')
+  statics = {quiet.names['geom'].index(n) for n in
+             ('ground', 'wall_nx', 'wall_px', 'wall_ny', 'wall_py')}
+  for g1, g2 in pairs:     # every surviving pair involves the pitch or the ball
+    assert {g1, g2} & (statics | {ball})
+  header = codegen.generate_header(quiet, codegen.TASK_NONE)
+  assert 'constexpr int NMASKW = 8;' in header and 'constexpr int NV = 254;' in header
+
+
+def test_scene_of_two_walkers_steps_like_two_single_walker_scenes():
+  """Two walkers that do not touch share nothing but the Newton solver's step
+  length and stopping rule (M is block diagonal, their rows are disjoint).
+  Teacher-forced per step the whole-scene solve must equal the two
+  single-walker solves to far below the parity bar -- the basis for advancing a
+  scene island by island: observed max 9e-14 over 300 steps with
+  contacts and joint limits active, although the iteration counts differ in
+  half of the steps.  (Free-running trajectories separate, as any two runs of a
+  falling humanoid that differ by 1e-14 do.)"""
+  pos = soccer.default_positions(2)
+  two = compiler.from_xml_string(soccer.build(2, with_ball=False))
+  ones = [compiler.from_xml_string(soccer.build(1, with_ball=False, walker_positions=[p]))
+          for p in pos]
+  nq1, nv1, nu1 = ones[0].nq, ones[0].nv, ones[0].nu
+  assert (two.nq, two.nv, two.nu) == (2*nq1, 2*nv1, 2*nu1)
+  rs = np.random.RandomState(0)
+  d2 = oracle.OracleData(oracle.OracleModel(two))
+  d1 = [oracle.OracleData(oracle.OracleModel(m)) for m in ones]
+  for k in range(2):
+    d2.qpos[k*nq1 + 2] = 0.95
+    d2.qvel[k*nv1:(k + 1)*nv1] = 0.3*rs.randn(nv1)
+  d2.step1()
+  worst, contacts, differ = 0.0, 0, 0
+  for _ in range(120):
+    c = rs.uniform(-1, 1, 2*nu1)
+    for k, d in enumerate(d1):
+      d.qpos[:] = d2.qpos[k*nq1:(k + 1)*nq1]
+      d.qvel[:] = d2.qvel[k*nv1:(k + 1)*nv1]
+      d.qacc_warmstart[:] = d2.qacc_warmstart[k*nv1:(k + 1)*nv1]
+      d.step1()
+      d.ctrl[:] = c[k*nu1:(k + 1)*nu1]
+    assert d2.ncon == d1[0].ncon + d1[1].ncon and d2.nefc == d1[0].nefc + d1[1].nefc
+    contacts += d2.ncon
+    d2.ctrl[:] = c
+    d2.physics_step()
+    for k, d in enumerate(d1):
+      d.physics_step()
+      v = d2.qvel[k*nv1:(k + 1)*nv1]
+      worst = max(worst, np.abs(v - d.qvel).max()/max(1.0, np.abs(d.qvel).max()))
+    differ += d2.solver_iter != max(d.solver_iter for d in d1)
+  assert contacts > 50 and not d2.warning.any()
+  assert worst <= 1e-11, worst
+
+
 def _states(m, nenv, rs, height):
   qpos = np.tile(m.qpos0, (nenv, 1))
   for i, (name, _, _, rng, _) in enumerate(T.JOINTS):
