@@ -28,7 +28,8 @@ _SUPPORTED_PAIRS = {
     (mdl.GEOM_PLANE, mdl.GEOM_SPHERE), (mdl.GEOM_PLANE, mdl.GEOM_CAPSULE),
     (mdl.GEOM_PLANE, mdl.GEOM_BOX), (mdl.GEOM_SPHERE, mdl.GEOM_SPHERE),
     (mdl.GEOM_SPHERE, mdl.GEOM_CAPSULE), (mdl.GEOM_CAPSULE, mdl.GEOM_CAPSULE),
-    (mdl.GEOM_SPHERE, mdl.GEOM_BOX),
+    (mdl.GEOM_SPHERE, mdl.GEOM_BOX), (mdl.GEOM_CAPSULE, mdl.GEOM_BOX),
+    (mdl.GEOM_BOX, mdl.GEOM_BOX),
 }
 
 

@@ -371,6 +371,12 @@ class Physics(_control.Physics):
   # ((max_batch, group), ...) in increasing max_batch; measured cross-overs per
   # domain (profiles/r02_kernel_shape_sweep.txt).
   _COOP_POLICY = ()
+  # fp64 cross-overs differ: the one-env-per-lane fp64 build of a contact model
+  # does not fit the register file (its per-lane arrays live in scratch: 134 MB
+  # of scratch traffic per cheetah launch), so the several-lanes kernel stays
+  # ahead up to larger batches (profiles/r03_f64_kernel_shape_sweep.txt).
+  # None: same as _COOP_POLICY.
+  _COOP_POLICY_F64 = None
   _GROUP = 64                 # lanes per env of build mode "coop" (128: two wavefronts)
 
   def __init__(self, model, batch_size=None, device=0, precision='f32',
@@ -392,7 +398,10 @@ class Physics(_control.Physics):
     self._build_mode = build_mode or self._BUILD_MODE
     self._group = group or self._GROUP
     if build_mode is None and self._build_mode == 'auto' and precision != 'mixed':
-      for max_batch, lanes in self._COOP_POLICY:
+      policy = self._COOP_POLICY
+      if precision == 'f64' and self._COOP_POLICY_F64 is not None:
+        policy = self._COOP_POLICY_F64
+      for max_batch, lanes in policy:
         if self._batch_size <= max_batch:
           self._build_mode, self._group = 'coop', lanes
           break

@@ -34,6 +34,7 @@ class Physics(engine.Physics):
   _TASK = codegen.TASK_CHEETAH
   # one env per wavefront up to 2048 envs (measured cross-over)
   _COOP_POLICY = ((1024, 128), (2048, 64))
+  _COOP_POLICY_F64 = ((4096, 128),)
 
   def speed(self):
     """Horizontal speed of the Cheetah (cheetah.py:55-57)."""

@@ -50,6 +50,7 @@ class Physics(engine.Physics):
   _TASK = codegen.TASK_HOPPER
   # one env per wavefront up to 2048 envs, two up to 4096 (measured cross-overs)
   _COOP_POLICY = ((1024, 128), (2048, 64), (4096, 32))
+  _COOP_POLICY_F64 = ((1024, 128), (8192, 32))
 
   def height(self):
     """Height of the torso's centre of mass above the foot's."""

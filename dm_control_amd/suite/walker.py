@@ -51,6 +51,7 @@ class Physics(engine.Physics):
   _TASK = codegen.TASK_WALKER
   # one env per wavefront up to 2048 envs, two up to 8192 (measured cross-overs)
   _COOP_POLICY = ((1024, 128), (2048, 64), (8192, 32))
+  _COOP_POLICY_F64 = ((1024, 128), (32768, 32))
 
   def torso_upright(self):
     return self.named.data.xmat['torso', 'zz']

@@ -791,6 +791,240 @@ static int capsule_capsule(RawCon* c, double margin, const double* pos1,
   return n;
 }
 
+/* capsule - box and box - box.  MuJoCo 2.0's own routines for these pairs
+ * (mjc_CapsuleBox, mjc_BoxBox) are part of the closed binary and the reference
+ * holds no value that pins their contact manifolds, so these two are OUR
+ * construction -- "parity unpinned": geometry checked against brute-force
+ * sampling of the surfaces and a force-balance KAT (tests/test_closed_form.py),
+ * not against libmujoco.  Conventions as for the other pairs: normal from
+ * geom 1 to geom 2, dist < 0 = penetration, pos = midpoint. */
+
+/* d/dt of f(t) = sum_k max(0, |c0_k + t a_k| - s_k)^2: squared distance from the
+ * point c0 + t a (box frame) to the box |x_k| <= s_k; nondecreasing in t */
+static double seg_box_slope(const double* c0, const double* a, const double* s,
+                            double t) {
+  double g = 0;
+  int k;
+  for (k = 0; k < 3; k++) {
+    double x = c0[k] + t*a[k];
+    if (x > s[k]) g += 2*a[k]*(x - s[k]);
+    else if (x < -s[k]) g += 2*a[k]*(x + s[k]);
+  }
+  return g;
+}
+/* parameters [tA, tB] (tA == tB unless a whole stretch is equally near) of the
+ * points of the segment c0 + t a, |t| <= h, nearest to the box.  f is convex and
+ * piecewise quadratic with breaks where the segment crosses a slab plane, so
+ * its slope is piecewise linear: evaluate it at the <= 8 break points. */
+static void seg_box_nearest(const double* c0, const double* a, double h,
+                            const double* s, double* tA, double* tB) {
+  double cand[8], g[8], tlo = -h, glo = 0, thi = h, ghi = 0, zlo = 0, zhi = 0;
+  int n = 0, k, i, sgn, haveneg = 0, havepos = 0, havezero = 0;
+  cand[n++] = -h; cand[n++] = h;
+  for (k = 0; k < 3; k++)
+    if (fabs(a[k]) > MINVAL)
+      for (sgn = -1; sgn <= 1; sgn += 2) {
+        double t = (sgn*s[k] - c0[k])/a[k];
+        if (t > -h && t < h) cand[n++] = t;
+      }
+  for (i = 0; i < n; i++) {
+    g[i] = seg_box_slope(c0, a, s, cand[i]);
+    if (g[i] < 0) {
+      if (!haveneg || cand[i] > tlo) { tlo = cand[i]; glo = g[i]; }
+      haveneg = 1;
+    } else if (g[i] > 0) {
+      if (!havepos || cand[i] < thi) { thi = cand[i]; ghi = g[i]; }
+      havepos = 1;
+    } else {
+      if (!havezero || cand[i] < zlo) zlo = cand[i];
+      if (!havezero || cand[i] > zhi) zhi = cand[i];
+      havezero = 1;
+    }
+  }
+  if (havezero) { *tA = zlo; *tB = zhi; }
+  else if (!haveneg) *tA = *tB = -h;            /* rising everywhere */
+  else if (!havepos) *tA = *tB = h;             /* falling everywhere */
+  else *tA = *tB = tlo + (thi - tlo)*(-glo)/(ghi - glo);
+}
+static int capsule_box(RawCon* c, double margin, const double* cpos,
+                       const double* cmat, const double* csize,
+                       const double* bpos, const double* bmat,
+                       const double* bsize) {
+  double axis[3] = {cmat[2], cmat[5], cmat[8]}, dif[3], c0[3], a[3], tA, tB, ts[4], p[3];
+  double h = csize[1];
+  int k, n = 0, nt = 0, i, j;
+  for (k = 0; k < 3; k++) dif[k] = cpos[k] - bpos[k];
+  for (k = 0; k < 3; k++) {   /* into the box frame */
+    c0[k] = bmat[k]*dif[0] + bmat[3 + k]*dif[1] + bmat[6 + k]*dif[2];
+    a[k] = bmat[k]*axis[0] + bmat[3 + k]*axis[1] + bmat[6 + k]*axis[2];
+  }
+  seg_box_nearest(c0, a, h, bsize, &tA, &tB);
+  ts[nt++] = tA;
+  if (tB - tA > 1e-9) ts[nt++] = tB;
+  else { ts[nt++] = -h; ts[nt++] = h; }   /* the ends, if they touch as well */
+  for (i = 0; i < nt && n < 2; i++) {
+    int dup = 0;
+    for (j = 0; j < i; j++) if (fabs(ts[i] - ts[j]) <= 1e-9) dup = 1;
+    if (dup) continue;
+    for (k = 0; k < 3; k++) p[k] = cpos[k] + axis[k]*ts[i];
+    if (sphere_box(c + n, margin, p, csize[0], bpos, bmat, bsize)) {
+      memcpy(c[n].frame + 3, axis, sizeof axis);
+      n++;
+    } else if (i == 0) {
+      return 0;             /* the nearest point is out of reach: so is the rest */
+    }
+  }
+  return n;
+}
+
+/* clips the polygon (u, v, d)[n] against u*sgn <= lim (axis 0) or v*sgn <= lim
+ * (axis 1); d (depth) is interpolated.  Sutherland-Hodgman, <= 8 vertices. */
+static int clip_poly(double (*poly)[3], int n, int axis, double sgn, double lim) {
+  double out[8][3];
+  int i, m = 0, k;
+  for (i = 0; i < n; i++) {
+    const double* A = poly[i];
+    const double* B = poly[(i + 1) % n];
+    double da = sgn*A[axis] - lim, db = sgn*B[axis] - lim;
+    if (da <= 0 && m < 8) { for (k = 0; k < 3; k++) out[m][k] = A[k]; m++; }
+    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+      double t = da/(da - db);
+      if (m < 8) { for (k = 0; k < 3; k++) out[m][k] = A[k] + t*(B[k] - A[k]); m++; }
+    }
+  }
+  memcpy(poly, out, sizeof(double)*3*(size_t)m);
+  return m;
+}
+static int box_box(RawCon* c, double margin, const double* p1, const double* m1,
+                   const double* s1, const double* p2, const double* m2,
+                   const double* s2) {
+  double R[3][3], AR[3][3], t[3], dw[3], best = -1e30, bestedge = -1e30, sep;
+  int i, j, k, code = -1, ecode = -1, n = 0;
+  double bsign = 1, esign = 1;
+  for (k = 0; k < 3; k++) dw[k] = p2[k] - p1[k];
+  for (i = 0; i < 3; i++) {
+    t[i] = m1[i]*dw[0] + m1[3 + i]*dw[1] + m1[6 + i]*dw[2];
+    for (j = 0; j < 3; j++) {
+      R[i][j] = m1[i]*m2[j] + m1[3 + i]*m2[3 + j] + m1[6 + i]*m2[6 + j];
+      AR[i][j] = fabs(R[i][j]) + 1e-12;
+    }
+  }
+  /* face axes of box 1, then of box 2: separation along +-axis */
+  for (i = 0; i < 3; i++) {
+    double rb = s2[0]*AR[i][0] + s2[1]*AR[i][1] + s2[2]*AR[i][2];
+    sep = fabs(t[i]) - (s1[i] + rb);
+    if (sep > best) { best = sep; code = i; bsign = t[i] < 0 ? -1 : 1; }
+  }
+  for (j = 0; j < 3; j++) {
+    double ra = s1[0]*AR[0][j] + s1[1]*AR[1][j] + s1[2]*AR[2][j];
+    double tj = t[0]*R[0][j] + t[1]*R[1][j] + t[2]*R[2][j];
+    sep = fabs(tj) - (ra + s2[j]);
+    if (sep > best) { best = sep; code = 3 + j; bsign = tj < 0 ? -1 : 1; }
+  }
+  /* edge x edge axes (skipped when the edges are parallel) */
+  for (i = 0; i < 3; i++)
+    for (j = 0; j < 3; j++) {
+      int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      double len = sqrt(1 - R[i][j]*R[i][j] > 0 ? 1 - R[i][j]*R[i][j] : 0), ra, rb, tl;
+      if (len < 1e-6) continue;
+      ra = s1[i1]*AR[i2][j] + s1[i2]*AR[i1][j];
+      rb = s2[j1]*AR[i][j2] + s2[j2]*AR[i][j1];
+      tl = t[i2]*R[i1][j] - t[i1]*R[i2][j];
+      sep = (fabs(tl) - (ra + rb))/len;
+      if (sep > bestedge) { bestedge = sep; ecode = 3*i + j; esign = tl < 0 ? -1 : 1; }
+    }
+  /* an edge pair wins only when clearly less penetrating than every face */
+  if (ecode >= 0 && bestedge > best + 1e-6 + 1e-3*fabs(best)) {
+    double nrm[3], e1[3], e2[3], c1[3], c2[3], w[3], b, d1, d2, den, u, v, q1[3], q2[3];
+    i = ecode/3; j = ecode % 3;
+    if (bestedge > margin) return 0;
+    for (k = 0; k < 3; k++) { e1[k] = m1[3*k + i]; e2[k] = m2[3*k + j]; }
+    cross3(nrm, e1, e2);
+    normalize3(nrm);
+    if (dot3(nrm, dw) < 0) for (k = 0; k < 3; k++) nrm[k] = -nrm[k];
+    (void)esign;
+    for (k = 0; k < 3; k++) { c1[k] = p1[k]; c2[k] = p2[k]; }
+    for (k = 0; k < 3; k++) {       /* supporting edges: towards / away from n */
+      double ax1[3] = {m1[k], m1[3 + k], m1[6 + k]}, ax2[3] = {m2[k], m2[3 + k], m2[6 + k]};
+      int q;
+      if (k != i) {
+        double sg = dot3(nrm, ax1) >= 0 ? 1 : -1;
+        for (q = 0; q < 3; q++) c1[q] += sg*s1[k]*ax1[q];
+      }
+      if (k != j) {
+        double sg = dot3(nrm, ax2) >= 0 ? -1 : 1;
+        for (q = 0; q < 3; q++) c2[q] += sg*s2[k]*ax2[q];
+      }
+    }
+    for (k = 0; k < 3; k++) w[k] = c1[k] - c2[k];
+    b = dot3(e1, e2); d1 = dot3(e1, w); d2 = dot3(e2, w);
+    den = 1 - b*b;
+    u = clampd((b*d2 - d1)/den, -s1[i], s1[i]);
+    v = clampd((d2 - b*d1)/den, -s2[j], s2[j]);
+    for (k = 0; k < 3; k++) { q1[k] = c1[k] + u*e1[k]; q2[k] = c2[k] + v*e2[k]; }
+    for (k = 0; k < 3; k++) w[k] = q2[k] - q1[k];
+    c->dist = dot3(w, nrm);
+    if (c->dist > margin) return 0;
+    memset(c->frame, 0, sizeof c->frame);
+    for (k = 0; k < 3; k++) { c->pos[k] = 0.5*(q1[k] + q2[k]); c->frame[k] = nrm[k]; }
+    return 1;
+  }
+  if (best > margin) return 0;
+  {
+    /* reference face on box `ref`, incident face on the other box */
+    const double *pr, *mr, *sr, *pi, *mi, *si;
+    double nout[3], poly[8][3], fc[3], ua[3], va[3], su, sv;
+    int ax = code % 3, inc = 0, iu, iv, cnt;
+    double most = 1e30;
+    if (code < 3) { pr = p1; mr = m1; sr = s1; pi = p2; mi = m2; si = s2; }
+    else { pr = p2; mr = m2; sr = s2; pi = p1; mi = m1; si = s1; bsign = -bsign; }
+    /* outward normal of the reference face (towards the other box) */
+    for (k = 0; k < 3; k++) nout[k] = bsign*mr[3*k + ax];
+    for (k = 0; k < 3; k++) fc[k] = pr[k] + nout[k]*sr[ax];
+    iu = (ax + 1) % 3; iv = (ax + 2) % 3;
+    for (k = 0; k < 3; k++) { ua[k] = mr[3*k + iu]; va[k] = mr[3*k + iv]; }
+    su = sr[iu]; sv = sr[iv];
+    /* incident face: the face of the other box whose normal opposes nout most */
+    for (k = 0; k < 3; k++) {
+      double axk[3] = {mi[k], mi[3 + k], mi[6 + k]}, d = dot3(axk, nout);
+      if (-fabs(d) < most) { most = -fabs(d); inc = k; bsign = d > 0 ? -1 : 1; }
+    }
+    {
+      int ju = (inc + 1) % 3, jv = (inc + 2) % 3, q, vtx;
+      static const int su4[4] = {1, -1, -1, 1}, sv4[4] = {1, 1, -1, -1};
+      for (vtx = 0; vtx < 4; vtx++) {
+        double wpt[3], rel[3];
+        for (q = 0; q < 3; q++)
+          wpt[q] = pi[q] + bsign*si[inc]*mi[3*q + inc] + su4[vtx]*si[ju]*mi[3*q + ju] +
+                   sv4[vtx]*si[jv]*mi[3*q + jv];
+        for (q = 0; q < 3; q++) rel[q] = wpt[q] - fc[q];
+        poly[vtx][0] = dot3(rel, ua); poly[vtx][1] = dot3(rel, va); poly[vtx][2] = dot3(rel, nout);
+      }
+    }
+    cnt = clip_poly(poly, 4, 0, 1, su);
+    cnt = clip_poly(poly, cnt, 0, -1, su);
+    cnt = clip_poly(poly, cnt, 1, 1, sv);
+    cnt = clip_poly(poly, cnt, 1, -1, sv);
+    {
+      int keep[8], nk = 0, take;
+      for (k = 0; k < cnt; k++) if (poly[k][2] <= margin) keep[nk++] = k;
+      for (take = 0; take < (nk < 4 ? nk : 4); take++) {
+        int idx = keep[nk <= 4 ? take : (take*nk)/4], q;
+        const double* v3 = poly[idx];
+        double dir = code < 3 ? 1 : -1;        /* normal from box 1 to box 2 */
+        c[n].dist = v3[2];
+        memset(c[n].frame, 0, sizeof c[n].frame);
+        for (q = 0; q < 3; q++) {
+          c[n].pos[q] = fc[q] + v3[0]*ua[q] + v3[1]*va[q] + 0.5*v3[2]*nout[q];
+          c[n].frame[q] = dir*nout[q];
+        }
+        n++;
+      }
+    }
+  }
+  return n;
+}
+
 static int pair_filtered(const mjoModel* m, int g1, int g2) {
   int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2], w1, w2, i;
   if (m->geom_type[g1] == GEOM_PLANE && m->geom_type[g2] == GEOM_PLANE)
@@ -854,6 +1088,10 @@ static void mjo_collision(const mjoModel* m, mjoData* d) {
         n = capsule_capsule(rc, margin, p1, m1, s1, p2, m2, s2);
       else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX)
         n = sphere_box(rc, margin, p1, s1[0], p2, m2, s2);
+      else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX)
+        n = capsule_box(rc, margin, p1, m1, s1, p2, m2, s2);
+      else if (t1 == GEOM_BOX && t2 == GEOM_BOX)
+        n = box_box(rc, margin, p1, m1, s1, p2, m2, s2);
       else
         continue; /* pair types rejected at compile time by the host */
       for (i = 0; i < n; i++) {

@@ -244,6 +244,67 @@ CAPSULE_OVER_PLANE = """
 """
 
 
+CAPSULE_NEAR_BOX = """
+<mujoco>
+  <option gravity="0 0 0"/>
+  <worldbody>
+    <body name="box" pos="0.1 -0.2 0.3" euler="20 -35 50">
+      <freejoint/>
+      <geom name="box" type="box" size="0.25 0.15 0.35" margin="5"/>
+    </body>
+    <body name="cap" pos="0 0 1.2">
+      <freejoint/>
+      <geom name="cap" type="capsule" size="0.06 0.3" margin="5"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+BOX_NEAR_BOX = """
+<mujoco>
+  <option gravity="0 0 0"/>
+  <worldbody>
+    <body name="a" pos="0 0 0">
+      <freejoint/>
+      <geom name="a" type="box" size="0.3 0.2 0.25"/>
+    </body>
+    <body name="b" pos="0 0 1">
+      <freejoint/>
+      <geom name="b" type="box" size="0.15 0.25 0.1"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+# three boxes stacked on the floor (the K3 balance, core_test.py:461-484, layer by
+# layer: each interface carries the weight of everything above it), and a
+# capsule lying on a box
+STACKED_BOXES = """
+<mujoco>
+  <option timestep="0.002"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="5 5 .1"/>
+    <body name="b0" pos="0 0 0.1">
+      <freejoint/>
+      <geom name="b0" type="box" size="0.3 0.3 0.1" mass="3"/>
+    </body>
+    <body name="b1" pos="0.03 -0.02 0.28">
+      <freejoint/>
+      <geom name="b1" type="box" size="0.2 0.22 0.08" mass="2"/>
+    </body>
+    <body name="b2" pos="0.01 0.02 0.42" euler="0 0 30">
+      <freejoint/>
+      <geom name="b2" type="box" size="0.1 0.12 0.06" mass="1"/>
+    </body>
+    <body name="log" pos="-0.05 0.03 0.53" euler="90 0 20">
+      <freejoint/>
+      <geom name="log" type="capsule" size="0.05 0.12" mass="0.5"/>
+    </body>
+  </worldbody>
+</mujoco>
+"""
+
+
 def closed_form_models():
   """name -> (compiled Model, build mode of its fp64 device code object)."""
   import numpy as np

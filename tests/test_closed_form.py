@@ -415,6 +415,150 @@ def test_sphere_box_narrowphase_against_brute_force():
   assert inside_seen == 20
 
 
+def _box_surface(size, n=121):
+  g = np.linspace(-1, 1, n)
+  u, v = np.meshgrid(g, g)
+  faces = []
+  for axis in range(3):
+    for sign in (-1, 1):
+      pts = np.zeros(u.shape + (3,))
+      pts[..., axis] = sign*size[axis]
+      pts[..., (axis + 1) % 3] = u*size[(axis + 1) % 3]
+      pts[..., (axis + 2) % 3] = v*size[(axis + 2) % 3]
+      faces.append(pts.reshape(-1, 3))
+  return np.concatenate(faces)
+
+
+def test_capsule_box_narrowphase_against_brute_force():
+  """Our capsule-box construction (oracle/mjstep.c `capsule_box`; MuJoCo's own
+  routine is in the closed binary: parity unpinned) vs dense sampling of the
+  segment and of the box surface: the FIRST contact is the nearest point of
+  the segment to the box (distance, direction), and when both end spheres
+  reach the box a second contact reports the other end."""
+  rs = np.random.RandomState(3)
+  m = compiler.from_xml_string(kat_models.CAPSULE_NEAR_BOX)
+  p = oracle.OraclePhysics(m)
+  box, cap = m.name2id('box', 'geom'), m.name2id('cap', 'geom')
+  size, (r, h) = m.geom_size[box], m.geom_size[cap][:2]
+  surface = _box_surface(size)
+  ts = np.linspace(-h, h, 401)
+  spacing = 2*max(size)/120
+  for trial in range(60):
+    p.reset()
+    bq, cq = _rand_quat(rs), _rand_quat(rs)
+    bpos = rs.uniform(-.2, .2, 3)
+    p.data.qpos[:] = np.concatenate([bpos, bq, bpos + rs.uniform(-.7, .7, 3), cq])
+    p.forward()
+    bmat = p.data.geom_xmat[box].reshape(3, 3)
+    cpos, axis = p.data.geom_xpos[cap], p.data.geom_xmat[cap].reshape(3, 3)[:, 2]
+    seg = cpos + np.outer(ts, axis)
+    loc = (seg - p.data.geom_xpos[box]) @ bmat              # box frame
+    if np.any(np.all(np.abs(loc) < size, axis=1)):
+      continue                                              # axis runs through the box
+    world = p.data.geom_xpos[box] + surface @ bmat.T
+    d = np.linalg.norm(seg[:, None] - world[None], axis=2)
+    i, k = np.unravel_index(np.argmin(d), d.shape)
+    assert p.data.ncon >= 1
+    con = p.data.contact(0)
+    want = d[i, k] - r
+    assert abs(con['dist'] - want) < 0.8*spacing, (trial, con['dist'], want)
+    if d[i, k] > 0.12:
+      towards = (world[k] - seg[i])/d[i, k]
+      assert np.dot(con['frame'][0], towards) > 1 - 2e-3, trial
+    for j in range(p.data.ncon):                            # every contact: a real distance
+      c = p.data.contact(j)
+      on_axis = c['pos'] - c['frame'][0]*(r + 0.5*c['dist'])   # back to the segment
+      t = np.dot(on_axis - cpos, axis)
+      assert abs(t) <= h + 1e-9
+      np.testing.assert_allclose(on_axis, cpos + t*axis, atol=1e-9)
+
+
+def test_box_box_narrowphase_properties():
+  """Our box-box construction (oracle/mjstep.c `box_box`: separating-axis test,
+  the incident face clipped against the reference face, or the closest points of
+  two edges; parity unpinned): no contact exactly when a sampled separating
+  distance is positive; for overlapping boxes the reported depth is the least
+  penetration over the face axes, every contact point lies within both boxes'
+  reach and the normal points from box 1 to box 2."""
+  rs = np.random.RandomState(4)
+  m = compiler.from_xml_string(kat_models.BOX_NEAR_BOX)
+  p = oracle.OraclePhysics(m)
+  sa, sb = m.geom_size[0], m.geom_size[1]
+  corners = np.array([[i, j, k] for i in (-1, 1) for j in (-1, 1) for k in (-1, 1)], float)
+  hits = misses = 0
+  for trial in range(300):
+    p.reset()
+    pa = rs.uniform(-.1, .1, 3)
+    pb = pa + rs.uniform(-.55, .55, 3)
+    p.data.qpos[:] = np.concatenate([pa, _rand_quat(rs), pb, _rand_quat(rs)])
+    p.forward()
+    ma, mb = (p.data.geom_xmat[g].reshape(3, 3) for g in (0, 1))
+    ca, cb = pa + (corners*sa) @ ma.T, pb + (corners*sb) @ mb.T
+    # separating-axis theorem by brute force over the 15 axes
+    axes = [ma[:, i] for i in range(3)] + [mb[:, i] for i in range(3)]
+    axes += [np.cross(ma[:, i], mb[:, j]) for i in range(3) for j in range(3)]
+    sep = -np.inf
+    for ax in axes:
+      nrm = np.linalg.norm(ax)
+      if nrm < 1e-6:
+        continue
+      ax = ax/nrm
+      a, b = ca @ ax, cb @ ax
+      sep = max(sep, b.min() - a.max(), a.min() - b.max())
+    if sep > 1e-9:
+      assert p.data.ncon == 0, (trial, sep)
+      misses += 1
+      continue
+    if sep > -1e-4:
+      continue                       # touching within rounding: either answer
+    hits += 1
+    assert 1 <= p.data.ncon <= 4, trial
+    for j in range(p.data.ncon):
+      c = p.data.contact(j)
+      assert c['dist'] <= 1e-12 and c['dist'] >= sep - 1e-6 - 0.06, (trial, c['dist'], sep)
+      assert np.dot(c['frame'][0], pb - pa) > -1e-9
+      for pos, mat, size in ((pa, ma, sa), (pb, mb, sb)):   # near both boxes
+        loc = (c['pos'] - pos) @ mat
+        assert np.all(np.abs(loc) <= size + abs(c['dist']) + 1e-9), trial
+    deepest = min(p.data.contact(j)['dist'] for j in range(p.data.ncon))
+    assert deepest <= 0.5*sep + 1e-9     # at least one point about as deep as the overlap
+  assert hits > 40 and misses > 40
+
+
+def test_stacked_boxes_carry_the_weight_above_them():
+  """K3 (core_test.py:461-484: sum of contact normal forces = weight) layer by
+  layer for a stack floor / box / box / box / capsule: after settling, the
+  normal forces across each interface add up to the weight of everything above
+  it -- box-box (face contacts, one stack member rotated 30 degrees), capsule-
+  box (a log lying on the top box) and plane-box."""
+  m = compiler.from_xml_string(kat_models.STACKED_BOXES)
+  p = oracle.OraclePhysics(m)
+  p.reset()
+  for _ in range(1500):
+    p.step()
+  assert not p.data.warning.any() and np.abs(p.data.qvel).max() < 1e-3
+  names = ['floor', 'b0', 'b1', 'b2', 'log']
+  ids = [m.name2id(n, 'geom') for n in names]
+  mass = {n: float(m.body_mass[m.geom_bodyid[g]]) for n, g in zip(names[1:], ids[1:])}
+  above = {('floor', 'b0'): sum(mass.values()),
+           ('b0', 'b1'): mass['b1'] + mass['b2'] + mass['log'],
+           ('b1', 'b2'): mass['b2'] + mass['log'], ('b2', 'log'): mass['log']}
+  force = {k: 0.0 for k in above}
+  counts = {k: 0 for k in above}
+  for i in range(p.data.ncon):
+    c = p.data.contact(i)
+    key = (names[ids.index(c['geom1'])], names[ids.index(c['geom2'])])
+    assert key in above, key            # nothing else touches
+    force[key] += p.data.contact_force(i)[0]
+    counts[key] += 1
+  for key, load in above.items():
+    np.testing.assert_allclose(force[key], 9.81*load, rtol=2e-3, err_msg=str(key))
+  assert counts[('floor', 'b0')] == 4 and counts[('b0', 'b1')] == 4
+  assert counts[('b1', 'b2')] >= 3 and counts[('b2', 'log')] == 2
+  # and the stack stands where it was built
+  assert abs(p.data.qpos[2] - 0.1) < 1e-3 and abs(p.data.qpos[7*3 + 2] - 0.53) < 5e-3
+
+
 def _textbook_cartpole_rhs(state, force, ipole):
   """Cart 1 kg, pole 0.1 kg with CoM at 0.5 m, theta = 0 upright, positive theta
   tips the pole towards +x (hinge axis +y); viscous damping on both joints."""

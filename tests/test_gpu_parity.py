@@ -343,9 +343,12 @@ def test_mixed_cartpole_free_run_1000_steps():
         'max %.2e share<=1e-4 %.3f (fp32: %.2e %.2e %.2e %.3f)' % (
             np.median(eq), np.percentile(eq, 90), eq.max(), np.mean(eq <= 1e-4),
             np.median(ef), np.percentile(ef, 90), ef.max(), np.mean(ef <= 1e-4)))
+  # observed on MI355X (round 3): mixed median 2.6e-6, p90 3.5e-5, 94.5 % within
+  # 1e-4; fp32 on the same starts 9.8e-6, 1.7e-4, 86.3 %
   assert np.median(eq) <= max(1.5*np.median(ef), 1e-6)
   assert np.mean(eq <= 1e-4) >= np.mean(ef <= 1e-4) - 0.02
-  assert np.median(eq) <= 1e-4 and np.percentile(eq, 90) <= 1.5e-3
+  assert np.median(eq) <= 3e-5 and np.percentile(eq, 90) <= 3.5e-4
+  assert np.mean(eq <= 1e-4) >= 0.85
 
 
 @pytest.mark.parametrize('key,mode', [(k, 'auto') for k in sorted(kat_models.GPU_MODELS)] +
@@ -1144,7 +1147,9 @@ def test_north_star_1000_step_free_run(name):
 # control steps after which the fp32 several-lanes free run is still compared
 # with a bound, and (median, max) asserted there
 EARLY = {'humanoid': 10, 'walker': 10, 'hopper': 25}
-FP32_EARLY = {'humanoid': (1e-3, 1e-1), 'walker': (1e-3, 1e-1), 'hopper': (1e-3, 1e-1)}
+# observed (median, max), MI355X round 3: humanoid 2.7e-6 / 1.5e-5 after 10 control
+# steps, walker 1.8e-6 / 4.3e-6 after 10, hopper 5.8e-7 / 1.4e-6 after 25
+FP32_EARLY = {'humanoid': (3e-5, 1.5e-4), 'walker': (2e-5, 5e-5), 'hopper': (6e-6, 1.5e-5)}
 
 
 @pytest.mark.parametrize('name,nsub,steps', [('humanoid', 5, 60), ('walker', 10, 100),
