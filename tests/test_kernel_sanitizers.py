@@ -71,13 +71,22 @@ def _run(exe, steps, qpos, qvel):
     # workspace tier under ASan; with real = double the low words are zero and
     # the trajectory must still be the oracle's
     ('cheetah', True, ('-DDMC_STATE_COMP=1',)),
-    ('cartpole', True, ('-DDMC_STATE_COMP=1',))])
+    ('cartpole', True, ('-DDMC_STATE_COMP=1',)),
+    # box-box (face contacts), capsule-box and plane-box in one stack
+    ('stacked_boxes', True, ()), ('stacked_boxes', False, ())])
 def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path):
   if name == 'primitives':
     model, task = compiler.from_xml_string(kat_models.PRIMITIVES), 0
     qpos, qvel = model.qpos0.copy(), np.zeros(model.nv)
     qpos[2], qpos[9], qpos[16] = 0.11, 0.2, 0.3     # stacked, in contact
     steps = 40
+  elif name == 'stacked_boxes':
+    model, task = compiler.from_xml_string(kat_models.STACKED_BOXES), 0
+    qpos, qvel = model.qpos0.copy(), np.zeros(model.nv)
+    qpos[7 + 3:7 + 7] = [0.98, 0.05, -0.1, 0.15]     # tilt one box: edge contacts too
+    qpos[7 + 3:7 + 7] /= np.linalg.norm(qpos[7 + 3:7 + 7])
+    qvel[:] = 0.3*np.random.RandomState(5).randn(model.nv)
+    steps = 60
   else:
     model, task = helpers.load_model(name), helpers.TASKS[name]
     q, v = helpers.initial_states(model, name, 4, seed=7)
@@ -176,7 +185,8 @@ def _build_coop(model, task, tmp_path, sanitizer, group):
     # mass-matrix / velocity wave, ThreadSanitizer watches their LDS regions
     ('humanoid', 'thread', 128, 9),
     ('hopper', 'thread', 128, 10),
-    ('humanoid', 'address,undefined', 128, 9)])
+    ('humanoid', 'address,undefined', 128, 9),
+    ('stacked_boxes', 'address,undefined', 64, 30)])
 def test_several_lanes_per_env_source(name, sanitizer, group, steps, tmp_path):
   """csrc/dmc_coop.hip with one thread per lane (tests/host_shim/shim_coop.h):
   a phase hand-over is a pthread barrier, so ThreadSanitizer reports any LDS
@@ -188,6 +198,10 @@ def test_several_lanes_per_env_source(name, sanitizer, group, steps, tmp_path):
     q = np.tile(model.qpos0, (nenv, 1))
     v = np.zeros((nenv, model.nv))
     q[:, 2], q[:, 9], q[:, 16] = 0.11, 0.2, 0.3
+  elif name == 'stacked_boxes':
+    model, task = compiler.from_xml_string(kat_models.STACKED_BOXES), 0
+    q = np.tile(model.qpos0, (nenv, 1))
+    v = 0.3*np.random.RandomState(5).randn(nenv, model.nv)
   else:
     model, task = helpers.load_model(name), helpers.TASKS[name]
     q, v = helpers.initial_states(model, name, max(nenv, 2), seed=7)
