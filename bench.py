@@ -97,19 +97,34 @@ def usable_cores():
   return n
 
 
+def _compiled_model(domain):
+  from dm_control_amd import suite as _suite  # host logic only (model compile)
+  from dm_control_amd.mjcf import compiler
+  xml, assets = getattr(_suite, domain).get_model_and_assets()
+  return compiler.from_xml_string(xml, assets)
+
+
+def load_env(domain, task, seed, environment_kwargs):
+  """`suite.load`, or -- `--domain soccer --task 2v2` -- BASELINE configs[4]:
+  `locomotion.soccer.load(team_size)` with humanoid walkers."""
+  if domain == 'soccer':
+    from dm_control_amd.locomotion import soccer
+    return soccer.load(int(task.split('v')[0]), random_state=seed,
+                       environment_kwargs=environment_kwargs)
+  from dm_control_amd import suite
+  return suite.load(domain, task, task_kwargs={'random': seed},
+                    environment_kwargs=environment_kwargs)
+
+
 def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None,
-                 free_run_steps=1000):
+                 free_run_steps=1000, gpu_batch_model=None):
   """Times the fp64 oracle (OpenMP over envs) on a bounded sample.
 
   With `gpu_batch` (the benchmarked batch) the same leg also reports the
   second half of BASELINE's metric, "qpos rel-err vs CPU mj_step".
   """
-  from dm_control_amd import suite as _suite  # host logic only (model compile)
-  from dm_control_amd.mjcf import compiler
   from oracle import oracle
-  mod = getattr(_suite, domain)
-  xml, assets = mod.get_model_and_assets()
-  model = compiler.from_xml_string(xml, assets)
+  model = gpu_batch_model if gpu_batch_model is not None else _compiled_model(domain)
   # rebuild the oracle natively for this host (the in-tree .so is generic x86-64)
   lib = None
   try:
@@ -121,7 +136,7 @@ def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None,
     lib = oracle.load()
   om = oracle.OracleModel(model, lib)
   cores = usable_cores()
-  nenv = 64*cores
+  nenv = (64 if model.nv < 100 else 2)*cores      # a 2v2 pitch is ~13 ms per physics step
   datas = [oracle.OracleData(om) for _ in range(nenv)]
   rs = np.random.RandomState(0)
   lim = model.jnt_limited.astype(bool)
@@ -152,8 +167,11 @@ def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None,
     out['qpos_rel_err'] = {
         'definition': 'max|q_gpu - q_cpu| / max(1, max|q_cpu|) per env; CPU = '
                       'fp64 oracle (KAT-pinned restatement, not libmujoco)',
-        'teacher_forced': _rel_err_sample(gpu_batch, om, oracle, nsub),
+        'teacher_forced': _rel_err_sample(gpu_batch, om, oracle, nsub,
+                                          nenv=64 if model.nv < 100 else 8,
+                                          steps=20 if model.nv < 100 else 4),
         'free_run': _free_run_sample(gpu_batch, om, oracle, nsub, cores,
+                                     nenv=64 if model.nv < 100 else 8,
                                      steps=free_run_steps)}
   return out
 
@@ -257,7 +275,7 @@ def _free_run_sample(gpu_batch, om, oracle, nsub, cores, nenv=64, steps=1000):
     left = alive & ~(e <= 1e-4)           # NaN counts as having left
     horizon[left] = t
     alive &= ~left
-    if t + 1 in (100, steps):
+    if t + 1 in (100, steps) or (steps < 100 and t + 1 == steps//2):
       marks['step_%d' % (t + 1)] = {
           'median': float(np.median(e)), 'p90': float(np.percentile(e, 90)),
           'max': float(e.max()), 'frac_within_1e-4': float(np.mean(e <= 1e-4))}
@@ -406,14 +424,10 @@ def measure(domain, task, precision, seeds, local_rank, steps, warmup, in_group)
   Returns (figures, env): the caller frees or reuses the env."""
   import torch
   import torch.distributed as dist
-  from dm_control_amd import suite
   nlocal = len(seeds)
-  env = suite.load(domain, task,
-                   task_kwargs={'random': int(seeds[0])},
-                   environment_kwargs={'batch_size': nlocal,
-                                       'device': local_rank,
-                                       'precision': precision,
-                                       'device_init': True})
+  env = load_env(domain, task, int(seeds[0]),
+                 {'batch_size': nlocal, 'device': local_rank,
+                  'precision': precision, 'device_init': True})
   physics, task_obj = env.physics, env.task
   batch = physics.batch
   info = batch.model.info
@@ -584,8 +598,10 @@ def main(argv=None):
         'envs_with_warnings': int((warn != 0).sum()),
     }
     if world == 1 and not args.no_cpu_baseline:
-      line['cpu_baseline'] = cpu_baseline(args.domain, args.task, nsub,
-                                          gpu_batch=batch)
+      line['cpu_baseline'] = cpu_baseline(
+          args.domain, args.task, nsub, gpu_batch=batch,
+          gpu_batch_model=physics.model,
+          free_run_steps=1000 if physics.model.nv < 100 else 40)
       line['tolerance'] = tolerance_verdict(
           line['dtype'], line['cpu_baseline']['qpos_rel_err']['free_run'])
   physics.free()
@@ -602,7 +618,8 @@ def main(argv=None):
       b64 = env64.physics.batch
       i64 = b64.model.info
       fr = cpu_baseline(args.domain, args.task, f64['nsub'], budget_s=1.0,
-                        gpu_batch=b64)['qpos_rel_err']
+                        gpu_batch=b64, gpu_batch_model=env64.physics.model,
+                        free_run_steps=1000 if env64.physics.model.nv < 100 else 40)['qpos_rel_err']
       bytes64 = algorithmic_bytes_per_env_step(i64, i64.real_size)*f64['nlocal']
       line['tolerance_compliant'] = {
           'dtype': 'f64', 'value': total_envs*fsteps/f64['elapsed'],

@@ -213,8 +213,13 @@ def capacities(m, pairs, ncon_max=None):
   worst_rows = 0
   mixed = [mix_pair(m, g1, g2) for g1, g2 in pairs]
   for (g1, g2), mx in zip(pairs, mixed):
-    n = (per_pair.get(int(m.geom_type[g2]), 1)
-         if m.geom_type[g1] == mdl.GEOM_PLANE else 1)
+    t1, t2 = int(m.geom_type[g1]), int(m.geom_type[g2])
+    if t1 == mdl.GEOM_PLANE:
+      n = per_pair.get(t2, 1)
+    elif t2 == mdl.GEOM_BOX and t1 in (mdl.GEOM_CAPSULE, mdl.GEOM_BOX):
+      n = 2 if t1 == mdl.GEOM_CAPSULE else 4     # capsule-box, box-box manifolds
+    else:
+      n = 1
     worst += n
     worst_rows += n*(1 if mx['dim'] == 1 else 2*(mx['dim'] - 1))
   nlimit = int(np.sum((np.asarray(m.jnt_limited) != 0) & np.isin(

@@ -1062,7 +1062,7 @@ struct Coop {
       const int p = base + l;
       RawCon rc[4] = {};
       int mask = 0;
-      if (p < NPAIR) mask = collide_pair(S + off::GEOM, p, rc);
+      if (p < NPAIR) mask = collide_pair(ArrPoses{S + off::GEOM}, p, rc);
       const int cnt = __builtin_popcount((unsigned)mask);
       int total;
       int slot = ncon + gscan(cnt, l, total);

@@ -82,7 +82,21 @@ using namespace dmc_model;
 
 constexpr int NM = NV*(NV + 1)/2;      // packed lower triangle
 constexpr int LANES = 64;               // envs per workgroup = one wavefront
-constexpr int MAT_REGS = NM > 0 ? NM : 1;
+// Packed nv x nv matrices (M, its factor, the Newton Hessian, Euler's M + h D)
+// are per-lane arrays -- registers in the unrolled build, private memory in the
+// rolled one -- while they fit: a lane's private segment ends at 128 KB on
+// gfx9.  Scenes with several walkers (a 2v2 soccer pitch: nv 254, 32385
+// entries per matrix) keep the four of them in the HBM workspace instead,
+// [entry][env] like the overflow rows (one-env-per-lane kernel only).
+#ifndef DMC_MAT_PRIVATE_BYTES
+#define DMC_MAT_PRIVATE_BYTES 16384
+#endif
+#ifdef DMC_COOP_BUILD
+constexpr bool MAT_IN_WS = false;
+#else
+constexpr bool MAT_IN_WS = (long long)NM*(long long)sizeof(real) > DMC_MAT_PRIVATE_BYTES;
+#endif
+constexpr int MAT_REGS = MAT_IN_WS ? 1 : (NM > 0 ? NM : 1);
 constexpr int NVX = NV > 0 ? NV : 1;
 constexpr int NUX = NU > 0 ? NU : 1;
 constexpr int NQX = NQ > 0 ? NQ : 1;
@@ -279,7 +293,8 @@ DEV int chol_factor_t(const Mat& A) {
   }
   return nbad;
 }
-DEV int chol_factor(const RegMat& A) { return chol_factor_t(A); }
+template <class Mat>
+DEV int chol_factor(const Mat& A) { return chol_factor_t(A); }
 
 template <class Mat>
 DEV void chol_solve(real* x, const Mat& L) {
@@ -308,7 +323,9 @@ struct Env {
   real qpos_lo[NQ > 0 ? NQ : 1], qvel_lo[NVX];   // low words of the fp64 state
 #endif
   real xpos[NBODY*3], xquat[NBODY*4], xmat[NBODY*9];
-  real xipos[NBODY*3], ximat[NBODY*9];
+  // (big scenes, MAT_IN_WS: the inertial frames are recomputed where com_pos
+  // needs them instead of being kept -- the fp64 frame must stay below 128 KB)
+  real xipos[NBODY*3], ximat[MAT_IN_WS ? 9 : NBODY*9];
   real xanchor[(NJNT > 0 ? NJNT : 1)*3], xaxis[(NJNT > 0 ? NJNT : 1)*3];
   real subtree_com[NBODY*3];
   real cinert[NBODY*10];
@@ -369,10 +386,24 @@ struct GlbRow {
 // tag and the low word is dropped)
 constexpr int WS_COMP = GLB_ROWS*RW + GLB_CONS*CW;
 #ifdef DMC_STATE_COMP
-constexpr int WS_WORDS = WS_COMP + 2*(NQ + NV);
+constexpr int WS_MAT = WS_COMP + 2*(NQ + NV);
 #else
-constexpr int WS_WORDS = WS_COMP;
+constexpr int WS_MAT = WS_COMP;
 #endif
+constexpr long long WS_GEOM = (long long)WS_MAT + (MAT_IN_WS ? 4LL*NM : 0LL);   // geom-pose mirror
+constexpr long long WS_WORDS_LL = WS_GEOM + (MAT_IN_WS ? 12LL*NGEOM : 0LL);
+static_assert(WS_WORDS_LL < (1LL << 31), "workspace words per env");
+constexpr int WS_WORDS = (int)WS_WORDS_LL;
+// a packed matrix in the workspace: entry i of env e at p[i*n]
+struct GlbMat {
+  real* p; long long n;
+  __device__ __forceinline__ real get(int i) const { return p[(long long)i*n]; }
+  __device__ __forceinline__ void set(int i, real x) const { p[(long long)i*n] = x; }
+};
+template <bool B, class T, class F> struct pick_ { typedef T type; };
+template <class T, class F> struct pick_<false, T, F> { typedef F type; };
+typedef pick_<MAT_IN_WS, GlbMat, RegMat>::type LaneMat;   // where a lane's matrices live
+enum { MAT_M = 0, MAT_L = 1, MAT_H = 2, MAT_A = 3 };
 
 struct Work {
   real* lds;   // LDS base + lane (rows, then contact records)
@@ -381,6 +412,9 @@ struct Work {
   __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*LANES}; }
   __device__ __forceinline__ GlbRow grow(int r) const {
     return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
+  }
+  __device__ __forceinline__ GlbMat mat(int k) const {
+    return GlbMat{glb + ((long long)WS_MAT + (long long)k*NM)*nenv, nenv};
   }
   __device__ __forceinline__ LdsRow lcon(int k) const {
     return LdsRow{lds + (LDS_ROWS*RW + k*CW)*LANES};
@@ -418,10 +452,17 @@ static __device__ __forceinline__ void for_rows_ahead(const Work& W, int nefc, L
     for (int r = LDS_ROWS; r < nefc; r++) use(load(W.grow(r)));
 }
 
-struct Mats {
+template <bool WS> struct MatsT {     // per-lane arrays
   static __device__ __forceinline__ RegMat M(Env& E, const Work&) { return RegMat{E.qM}; }
   static __device__ __forceinline__ RegMat L(Env& E, const Work&) { return RegMat{E.qL}; }
+  static __device__ __forceinline__ RegMat local(real* a, const Work&, int) { return RegMat{a}; }
 };
+template <> struct MatsT<true> {       // HBM workspace
+  static __device__ __forceinline__ GlbMat M(Env&, const Work& W) { return W.mat(MAT_M); }
+  static __device__ __forceinline__ GlbMat L(Env&, const Work& W) { return W.mat(MAT_L); }
+  static __device__ __forceinline__ GlbMat local(real*, const Work& W, int k) { return W.mat(k); }
+};
+typedef MatsT<MAT_IN_WS> Mats;
 
 // ---------------------------------------------------------------------------
 // position stage: kinematics, centre-of-mass frame, composite inertia
@@ -508,7 +549,7 @@ DEV void kinematics(Env& E) {
     DMC_UNROLL
     for (int k = 0; k < 3; k++) E.xipos[3*i + k] = xpos[k] + v[k];
     mulquat(q, xquat, iq);
-    quat2mat(E.ximat + 9*i, q);
+    if (!MAT_IN_WS) quat2mat(E.ximat + 9*i, q);
   }
 }
 
@@ -539,7 +580,15 @@ DEV void com_pos(Env& E) {
   DMC_UNROLL
   for (int i = 1; i < NBODY; i++) {
     const real* com = E.subtree_com + 3*body_rootid[i];
-    const real* mat = E.ximat + 9*i;
+    real mat_[9];
+    if (MAT_IN_WS) {     // same two operations as in kinematics(), on the stored xquat
+      const real iq[4] = {R(body_iquat[4*i]), R(body_iquat[4*i + 1]),
+                          R(body_iquat[4*i + 2]), R(body_iquat[4*i + 3])};
+      real q[4];
+      mulquat(q, E.xquat + 4*i, iq);
+      quat2mat(mat_, q);
+    }
+    const real* mat = MAT_IN_WS ? mat_ : E.ximat + 9*i;
     real dif[3], t[9];
     const real mass = R(body_mass[i]);
     const real in0 = R(body_inertia[3*i]), in1 = R(body_inertia[3*i + 1]),
@@ -940,27 +989,50 @@ DEV int sphere_sphere(RawCon* c, real margin, const real* p1, const real* p2,
 // world poses of all geoms, computed once per step: G[12*g] = pos(3), mat(9).
 // The narrowphase reads only this mirror, so a rolled pair loop (large models)
 // indexes G dynamically while Env itself stays statically indexed.
-DEV void geom_poses(const Env& E, real* G) {
+// where the mirror lives: a per-lane array, or -- big scenes -- the workspace
+struct ArrPoses {
+  real* p;
+  __device__ __forceinline__ real get(int i) const { return p[i]; }
+  __device__ __forceinline__ void set(int i, real x) const { p[i] = x; }
+};
+struct WsPoses {
+  real* p; long long n;
+  __device__ __forceinline__ real get(int i) const { return p[(long long)i*n]; }
+  __device__ __forceinline__ void set(int i, real x) const { p[(long long)i*n] = x; }
+};
+template <bool WS> struct PoseSrc {
+  static __device__ __forceinline__ ArrPoses make(const Work&, real* local) { return ArrPoses{local}; }
+};
+template <> struct PoseSrc<true> {
+  static __device__ __forceinline__ WsPoses make(const Work& W, real*) {
+    return WsPoses{W.glb + WS_GEOM*W.nenv, W.nenv};
+  }
+};
+template <class Poses>
+DEV void geom_poses(const Env& E, const Poses& G) {
   DMC_UNROLL
   for (int g = 0; g < NGEOM; g++) {
     const int b = geom_bodyid[g];
     real gp[3] = {R(geom_pos[3*g]), R(geom_pos[3*g + 1]), R(geom_pos[3*g + 2])};
     real gq[4] = {R(geom_quat[4*g]), R(geom_quat[4*g + 1]), R(geom_quat[4*g + 2]),
                   R(geom_quat[4*g + 3])};
-    real v[3], q[4];
+    real v[3], q[4], mat[9];
     mulmatvec3(v, E.xmat + 9*b, gp);
     DMC_UNROLL
-    for (int k = 0; k < 3; k++) G[12*g + k] = E.xpos[3*b + k] + v[k];
+    for (int k = 0; k < 3; k++) G.set(12*g + k, E.xpos[3*b + k] + v[k]);
     mulquat(q, E.xquat + 4*b, gq);
     normalize4(q);
-    quat2mat(G + 12*g + 3, q);
+    quat2mat(mat, q);
+    DMC_UNROLL
+    for (int k = 0; k < 9; k++) G.set(12*g + 3 + k, mat[k]);
   }
 }
-DEV void geom_pose(const real* G, int g, real* pos, real* mat) {
+template <class Poses>
+DEV void geom_pose(const Poses& G, int g, real* pos, real* mat) {
   DMC_UNROLL
-  for (int k = 0; k < 3; k++) pos[k] = G[12*g + k];
+  for (int k = 0; k < 3; k++) pos[k] = G.get(12*g + k);
   DMC_UNROLL
-  for (int k = 0; k < 9; k++) mat[k] = G[12*g + 3 + k];
+  for (int k = 0; k < 9; k++) mat[k] = G.get(12*g + 3 + k);
 }
 
 // rc[cnt] = c (cnt <= 3).  The several-lanes-per-env build writes it as
@@ -1272,7 +1344,8 @@ DEV int box_box(RawCon* rc, real margin, const real* p1, const real* m1, const r
 }
 
 // narrowphase of static pair p; returns a bit mask of valid contact slots
-DEV int collide_pair(const real* G, int p, RawCon* rc) {
+template <class Poses>
+DEV int collide_pair(const Poses& G, int p, RawCon* rc) {
   const int g1 = pair_g1[p], g2 = pair_g2[p];
   const int t1 = geom_type[g1], t2 = geom_type[g2];
   const real margin = R(pair_margin[p]);
@@ -1401,7 +1474,8 @@ DEV void write_contact(const Rec& rec, int p, const RawCon& c) {
 // phase 1: narrowphase over the static pair list -> compact contact list
 DEV void detect_contacts(Env& E, const Work& W) {
   if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return;
-  real G[NGEOM*12];
+  real Garr[MAT_IN_WS ? 1 : NGEOM*12];
+  const auto G = PoseSrc<MAT_IN_WS>::make(W, Garr);
   geom_poses(E, G);
   DMC_UNROLL_PAIRS
   for (int p = 0; p < NPAIR; p++) {
@@ -1598,10 +1672,10 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
 #endif
   real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], Hreg[MAT_REGS];
   const auto M = Mats::M(E, W);
-  const RegMat H{Hreg};
+  const LaneMat H = Mats::local(Hreg, W, MAT_H);
   // the factor of M is dead once qacc_smooth has been solved: its registers
   // take the factor of the Hessian
-  const RegMat F = Mats::L(E, W);
+  const LaneMat F = Mats::L(E, W);
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
   symv(Ma, M, E.qacc);
@@ -2009,7 +2083,7 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
     if (damped) {
       real Areg[MAT_REGS];
       const auto M = Mats::M(E, W);
-      const RegMat A{Areg};
+      const LaneMat A = Mats::local(Areg, W, MAT_A);
       DMC_UNROLL
       for (int i = 0; i < NM; i++) A.set(i, M.get(i));
       DMC_UNROLL

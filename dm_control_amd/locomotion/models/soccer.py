@@ -19,7 +19,35 @@ from dm_control_amd.suite import models as m
 
 PHYSICS_TIMESTEP = 0.005           # soccer/task.py:105
 BALL = dict(radius=0.35, mass=0.045, friction=(0.7, 0.075, 0.075), damp_ratio=1.0)
+# `regulation_soccer_ball()` (soccer_ball.py:27-47), what soccer.load pairs with
+# humanoid walkers (soccer/__init__.py:130-136): a size-5 ball
+REGULATION_BALL = dict(radius=0.117, mass=0.45, friction=(0.7, 0.05, 0.04), damp_ratio=0.4)
 PITCH_SIZE = (9.0, 6.0)            # half extents of the fixed arena (m)
+
+# Goal frame as capsules in the unit cube facing +x (what pitch.py:55-64 lists as
+# `fromto` sextuples): name -> (from corner, to corner)
+GOAL_FRAME = (
+    ('right_post', (1, -1, -1), (1, -1, 1)), ('left_post', (1, 1, -1), (1, 1, 1)),
+    ('top_post', (1, -1, 1), (1, 1, 1)), ('right_base', (1, -1, -1), (-1, -1, -1)),
+    ('left_base', (1, 1, -1), (-1, 1, -1)), ('back_base', (-1, -1, -1), (-1, 1, -1)),
+    ('right_support', (-1, -1, -1), (.2, -1, 1)), ('right_top_support', (.2, -1, 1), (1, -1, 1)),
+    ('left_support', (-1, 1, -1), (.2, 1, 1)), ('left_top_support', (.2, 1, 1), (1, 1, 1)))
+
+
+def goal_frame_capsules(pos, size, direction):
+  """(name, fromto, radius) of the ten capsules of one goal (pitch.py:165-198,
+  236-276): the unit-cube frame mirrored in x and y for `direction` = -1, scaled
+  by the goal's half sizes and moved to `pos`; radius 7 % of the mean half size,
+  the crossbar 1 % thicker, the supports 25 % thinner."""
+  radius = 0.07*sum(size)/3.0
+  flip = (direction, direction, 1)
+  out = []
+  for name, a, b in GOAL_FRAME:
+    fromto = tuple(pos[k] + flip[k]*a[k]*size[k] for k in range(3)) + \
+             tuple(pos[k] + flip[k]*b[k]*size[k] for k in range(3))
+    r = radius*(1.01 if 'top' in name else 1.0)*(0.75 if 'support' in name else 1.0)
+    out.append((name, fromto, r))
+  return out
 
 
 def default_positions(num_walkers):
@@ -30,7 +58,8 @@ def default_positions(num_walkers):
 
 def build(num_walkers=1, with_ball=True, pitch_size=PITCH_SIZE,
           nconmax_per_player=200, njmax_per_player=200,
-          walker_positions=None, disable_walker_contacts=False):
+          walker_positions=None, disable_walker_contacts=False, ball=None,
+          goal_size=None, field_box_offset=0.0):
   """MJCF string of the scene.  Walkers stand in a row facing the ball.
 
   walker_positions: root positions, default `default_positions(num_walkers)`.
@@ -38,6 +67,11 @@ def build(num_walkers=1, with_ball=True, pitch_size=PITCH_SIZE,
   (soccer/task.py:29-33, 84-85): `contype=0` on every walker geom, so walkers
   touch the pitch and the ball (whose contype matches the walkers'
   conaffinity) but neither each other nor themselves.
+
+  ball: parameter dict (`BALL` by default, `REGULATION_BALL` for humanoid games).
+  goal_size: (depth, half width, half height) of the two goals; adds their
+  frames (ten capsules each, fixed to the world) where Pitch._build puts them
+  (pitch.py:426-447).  None: no goal frames.
 
   A 2v2 scene is nq 259, nv 254, nu 224: it compiles, generates
   a kernel header (dof sets are multi-word) and steps on the CPU oracle; the
@@ -62,12 +96,20 @@ def build(num_walkers=1, with_ball=True, pitch_size=PITCH_SIZE,
   for name, pos, xyaxes in walls:
     m.node(world, 'geom', name=name, pos=pos, xyaxes=xyaxes, size=(max(lx, ly), 3.0, 0.1),
            **plane)
+  if goal_size is not None:
+    posts = dict(type='capsule', condim=3, friction=(1, 0.005, 0.0001),
+                 solref=(0.02, 1), solimp=(0.9, 0.95, 0.001))
+    for prefix, direction, x in (('home_goal', 1, -lx + goal_size[0] + field_box_offset),
+                                 ('away_goal', -1, lx - goal_size[0] - field_box_offset)):
+      for name, fromto, r in goal_frame_capsules((x, 0.0, goal_size[2]), goal_size, direction):
+        m.node(world, 'geom', name='%s/%s' % (prefix, name), fromto=fromto, size=(r,), **posts)
   if with_ball:
-    ball = m.node(world, 'body', name='ball', pos=(0, 0, BALL['radius'] + 0.01))
-    m.node(ball, 'freejoint', name='ball_free')
-    m.node(ball, 'geom', name='ball', type='sphere', size=(BALL['radius'],), condim=6,
-           priority=1, mass=BALL['mass'], friction=BALL['friction'],
-           solref=(0.02, BALL['damp_ratio']), solimp=(0.9, 0.95, 0.001))
+    prm = BALL if ball is None else ball
+    body = m.node(world, 'body', name='ball', pos=(0, 0, prm['radius'] + 0.01))
+    m.node(body, 'freejoint', name='ball_free')
+    m.node(body, 'geom', name='ball', type='sphere', size=(prm['radius'],), condim=6,
+           priority=1, mass=prm['mass'], friction=prm['friction'],
+           solref=(0.02, prm['damp_ratio']), solimp=(0.9, 0.95, 0.001))
   if walker_positions is None:
     walker_positions = default_positions(num_walkers)
   for i in range(num_walkers):

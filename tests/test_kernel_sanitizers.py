@@ -72,6 +72,10 @@ def _run(exe, steps, qpos, qvel):
     # the trajectory must still be the oracle's
     ('cheetah', True, ('-DDMC_STATE_COMP=1',)),
     ('cartpole', True, ('-DDMC_STATE_COMP=1',)),
+    # the packed matrices in the HBM workspace (the path of scenes with several
+    # walkers, forced here on small models)
+    ('cheetah', False, ('-DDMC_MAT_PRIVATE_BYTES=64',)),
+    ('primitives', False, ('-DDMC_MAT_PRIVATE_BYTES=64',)),
     # box-box (face contacts), capsule-box and plane-box in one stack
     ('stacked_boxes', True, ()), ('stacked_boxes', False, ())])
 def test_kernel_source_is_clean_and_matches_oracle(name, unroll, extra, tmp_path):

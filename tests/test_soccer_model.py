@@ -299,3 +299,118 @@ def test_ball_scene_on_device_matches_oracle():
   assert not hb.read(W.FIELD_WARN).any()
   assert e.max() <= 1e-9, e.max()
   hb.free()
+
+
+def _pitch_model(quiet):
+  from dm_control_amd.locomotion import soccer as soccer_env
+  return compiler.from_xml_string(soccer.build(
+      4, pitch_size=soccer_env.area_to_size(400.0), disable_walker_contacts=quiet,
+      ball=soccer.REGULATION_BALL, goal_size=soccer_env.MINI_FOOTBALL_GOAL_SIZE))
+
+
+def _pitch_states(m, nenv, rs):
+  """Players standing on / sunk a little into the pitch or lying on it, joints
+  off their zero pose, the ball resting against a foot of player 0 (so that a
+  ball-walker contact couples two trees) or in the air."""
+  qpos = np.tile(m.qpos0, (nenv, 1))
+  qvel = 0.2*rs.randn(nenv, m.nv)
+  for e in range(nenv):
+    for k in range(4):
+      a = 7 + 63*k
+      qpos[e, a + 7:a + 63] += 0.15*rs.randn(56)
+      if (e + k) % 3 == 2:        # lying on the back / side
+        qpos[e, a + 2] = 0.25
+        qpos[e, a + 3:a + 7] = [1, 0, 0, 0] + 0.05*rs.randn(4)
+        qpos[e, a + 3:a + 7] /= np.linalg.norm(qpos[e, a + 3:a + 7])
+      else:                       # standing, feet at / slightly in the ground
+        qpos[e, a + 2] = rs.uniform(0.93, 1.0)
+    foot = qpos[e, 7:9]
+    qpos[e, 0:2] = foot + (rs.uniform(-0.25, 0.25, 2) if e % 2 == 0 else [3.0, 1.0])
+    qpos[e, 2] = 0.115 if e % 2 == 0 else 0.6
+  return qpos, qvel
+
+
+@pytest.mark.gpu
+def test_single_walker_fp64_at_full_contact_capacity():
+  """The 62-dof walker in fp64 from standing and lying poses with every contact
+  row in play (the several-lanes fp64 build above only has room for four
+  contacts): the one-env-per-lane kernel in its rolled form, rows beyond the
+  LDS tier in the HBM workspace."""
+  from dm_control_amd import build, wrapper as W
+  m = _walker_model()
+  rs = np.random.RandomState(4)
+  hm = W.HipModel(build.build_model(m, 0, 'f64', mode='rolled'))
+  hb = W.HipBatch(hm, 12)
+  qpos, qvel = _states(m, 12, rs, height=1.0)
+  qpos[6:, 2] = 0.2
+  qpos[6:, 3:7] = [1, 0, 0, 0]
+  e, rows = _teacher_forced(m, hb, qpos, qvel, 8, rs, W)
+  stats = hb.read(W.FIELD_STATS)
+  print('OBSERVED soccer walker f64 rolled, full capacity: max %.2e, ncon up to %d' % (
+      e.max(), stats[0].max()))
+  assert stats[0].max() > 4 and rows > 12*8*10
+  assert not hb.read(W.FIELD_WARN).any()
+  assert e.max() <= 1e-9, e.max()
+  hb.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('quiet', [True, False])
+def test_two_by_two_pitch_on_device_matches_oracle(quiet):
+  """BASELINE configs[4]: the 2v2 pitch (nq 259, nv 254, nu 224; four CMU
+  humanoids, regulation ball, two goal frames) as ONE model on the device: the
+  one-env-per-lane kernel, generic loops, the four packed 254 x 254 matrices and
+  the geom-pose mirror of each pitch in the HBM workspace.  fp64 per step
+  against the oracle at full contact capacity, with walker-pitch, walker-ball
+  and (quiet=False) walker-walker / self contacts; fp32 statistics."""
+  from dm_control_amd import build, wrapper as W
+  m = _pitch_model(quiet)
+  assert (m.nq, m.nv, m.nu) == (259, 254, 224)
+  rs = np.random.RandomState(7)
+  nenv = 6
+  qpos, qvel = _pitch_states(m, nenv, rs)
+  if not quiet:                   # two players into each other
+    qpos[:, 7 + 63:7 + 63 + 2] = qpos[:, 7:9] + [0.25, 0.1]
+  hm = W.HipModel(build.build_model(m, 0, 'f64', ncon_max=64, mode='rolled'))
+  hb = W.HipBatch(hm, nenv)
+  e, rows = _teacher_forced(m, hb, qpos, qvel, 5, np.random.RandomState(1), W)
+  stats = hb.read(W.FIELD_STATS)
+  print('OBSERVED 2v2 pitch f64 (quiet=%s): per-step max %.2e; ncon up to %d, nefc up to %d'
+        % (quiet, e.max(), stats[0].max(), stats[1].max()))
+  assert not hb.read(W.FIELD_WARN).any()
+  assert stats[0].max() >= 6 and rows > nenv*5*40
+  assert e.max() <= 1e-9, e.max()
+  hb.free()
+  hm32 = W.HipModel(build.build_model(m, 0, 'f32', ncon_max=64, mode='rolled'))
+  hb = W.HipBatch(hm32, nenv)
+  e32, _ = _teacher_forced(m, hb, qpos, qvel, 5, np.random.RandomState(1), W)
+  print('OBSERVED 2v2 pitch f32 (quiet=%s): per-step median %.2e p90 %.2e max %.2e'
+        % (quiet, np.median(e32), np.percentile(e32, 90), e32.max()))
+  assert np.median(e32) <= 2e-4 and np.isfinite(e32).all()
+  hb.free()
+
+
+@pytest.mark.gpu
+def test_soccer_environment_plays():
+  """`locomotion.soccer.load(2)` end to end on the device: 48 pitches, random
+  actions for 40 control steps (200 physics steps): no warning bits, finite
+  state, one observation dict and one reward per player, actions as a list."""
+  from dm_control_amd.locomotion import soccer as soccer_env
+  env = soccer_env.load(2, random_state=3, disable_walker_contacts=True,
+                        environment_kwargs={'batch_size': 48})
+  assert len(env.action_spec()) == 4 and env.action_spec()[0].shape == (56,)
+  ts = env.reset()
+  assert ts.first() and len(ts.observation) == 4
+  rs = np.random.RandomState(0)
+  for _ in range(40):
+    ts = env.step([rs.uniform(-1, 1, (48, 56)) for _ in range(4)])
+  assert len(ts.reward) == 4 and ts.reward[0].shape == (48,)
+  assert ts.discount.shape == (48,)
+  for obs in ts.observation:
+    for key, value in obs.items():
+      assert np.isfinite(value).all(), key
+  assert obs['ball_ego_position'].shape == (48, 3)
+  assert not np.asarray(env.physics.data.warning_mask).any()
+  z = np.asarray(env.physics.data.qpos)[:, [7 + 63*k + 2 for k in range(4)]]
+  assert (z > 0.05).all() and (z < 1.6).all()
+  env.physics.free()

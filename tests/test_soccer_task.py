@@ -1,0 +1,196 @@
+"""Game logic and observables of the batched soccer task on a recording fake
+Physics (CPU): what `dm_control.locomotion.soccer` computes in Python around
+the physics step -- goal / off-court detection (pitch.py:426-457, 574-583),
+rewards and discount (task.py:161-200), throw-in (task.py:117-124), kick-off
+(initializers.py:32-120) and the egocentric observables of
+`CoreObservablesAdder` (observables.py:59-240; frame rule composer/entity.py:
+340-375).  The reference classes themselves need PyMJCF + libmujoco to
+instantiate, so the expectations here are the formulas of those files worked
+by hand, not recorded outputs ("parity unpinned" for this layer)."""
+
+import numpy as np
+import pytest
+
+from dm_control_amd.locomotion import soccer
+from dm_control_amd.locomotion.models import soccer as scene
+from dm_control_amd.mjcf import compiler
+
+
+class _Data:
+  pass
+
+
+class FakePhysics:
+  """qpos / qvel holder with the accessors the task uses."""
+
+  def __init__(self, model, batch):
+    self.model = model
+    self.batch_size = batch
+    self.data = _Data()
+    self.data.qpos = np.tile(model.qpos0, (batch, 1))
+    self.data.qvel = np.zeros((batch, model.nv))
+    self.control = None
+
+  def set_state(self, state):
+    self.data.qpos = state[:, :self.model.nq].copy()
+    self.data.qvel = state[:, self.model.nq:].copy()
+
+  def set_control(self, action):
+    self.control = np.asarray(action)
+
+
+@pytest.fixture(scope='module')
+def model():
+  return compiler.from_xml_string(scene.build(
+      4, disable_walker_contacts=True, ball=scene.REGULATION_BALL,
+      goal_size=soccer.MINI_FOOTBALL_GOAL_SIZE, pitch_size=(12.0, 9.0)))
+
+
+def _task(seed=0, **kw):
+  pitch = soccer.PitchGeometry((12.0, 9.0), soccer.MINI_FOOTBALL_GOAL_SIZE)
+  return soccer.Task(2, pitch, random=seed, **kw), pitch
+
+
+def test_pitch_detector_boxes():
+  gd, gw, gh = soccer.MINI_FOOTBALL_GOAL_SIZE
+  assert (gd, gw, gh) == (0.61, 1.83, 0.61)
+  _, pitch = _task()
+  np.testing.assert_allclose(pitch.home_goal[2], [-12 + gd, 0, gh])
+  np.testing.assert_allclose(pitch.away_goal[0], [12 - 2*gd, -gw, 0])
+  np.testing.assert_allclose(pitch.away_goal[1], [12, gw, 2*gh])
+  np.testing.assert_allclose(pitch.field[1], [12 - 2*gd, 9 - 2*gd])
+  assert soccer.area_to_size(400.0) == pytest.approx((np.sqrt(400/0.75)/2, np.sqrt(300.0)/2))
+  # the goal frame: ten capsules per goal, the away one mirrored in x and y
+  home = scene.goal_frame_capsules((-12 + gd, 0, gh), (gd, gw, gh), 1)
+  away = scene.goal_frame_capsules((12 - gd, 0, gh), (gd, gw, gh), -1)
+  assert len(home) == len(away) == 10
+  post = dict((n, (f, r)) for n, f, r in home)
+  np.testing.assert_allclose(post['right_post'][0], [-12 + 2*gd, -gw, 0, -12 + 2*gd, -gw, 2*gh])
+  assert post['top_post'][1] == pytest.approx(0.07*(gd + gw + gh)/3*1.01)
+  assert post['left_support'][1] == pytest.approx(0.07*(gd + gw + gh)/3*0.75)
+  np.testing.assert_allclose(dict((n, f) for n, f, _ in away)['right_post'],
+                             [12 - 2*gd, gw, 0, 12 - 2*gd, gw, 2*gh])
+
+
+def test_kickoff_keeps_everyone_apart_and_inside_the_spawn_range(model):
+  task, pitch = _task(seed=3)
+  p = FakePhysics(model, 16)
+  task.initialize_episode(p)
+  q = p.data.qpos
+  span = np.array(pitch.size)*soccer.SPAWN_RATIO
+  pts = [q[:, 0:2]] + [q[:, 7 + 63*k:9 + 63*k] for k in range(4)]
+  for a in range(5):
+    assert np.all(np.abs(pts[a]) <= span)
+    for b in range(a):
+      assert np.all(np.linalg.norm(pts[a] - pts[b], axis=1) > 1.0)
+  np.testing.assert_allclose(q[:, 2], soccer.INIT_BALL_Z)
+  for k in range(4):          # upright: the walker's up axis stays the world z axis
+    quat = q[:, 10 + 63*k:14 + 63*k]
+    np.testing.assert_allclose(np.linalg.norm(quat, axis=1), 1.0)
+    up0 = soccer._quat_to_mat(model.qpos0[None, 10 + 63*k:14 + 63*k])[0]
+    up = soccer._quat_to_mat(quat)
+    np.testing.assert_allclose(up[:, 2, :] @ up0[2, :], 1.0, atol=1e-12)
+  assert not np.any(p.data.qvel)
+
+
+def test_goals_rewards_discount_and_restart(model):
+  task, pitch = _task(seed=1)
+  p = FakePhysics(model, 4)
+  task.initialize_episode(p)
+  p.data.qpos[1, 0:3] = pitch.away_goal[2]              # home team scores on pitch 1
+  p.data.qpos[2, 0:3] = pitch.home_goal[2] + [0.1, -1.0, 0.2]   # away scores on pitch 2
+  p.data.qpos[3, 0:3] = pitch.away_goal[2] + [0, 0, 0.7]  # over the crossbar: no goal
+  task.after_step(p)
+  rew = task.get_reward(p)
+  assert len(rew) == 4 and rew[0].dtype == np.float32
+  np.testing.assert_array_equal(rew[0], [0, 1, -1, 0])        # home players
+  np.testing.assert_array_equal(rew[1], [0, 1, -1, 0])
+  np.testing.assert_array_equal(rew[2], [0, -1, 1, 0])        # away players
+  np.testing.assert_array_equal(task.discount(p), [1, 0, 0, 1])
+  assert task.get_termination(p) is None
+  before = p.data.qpos.copy()
+  task.before_step([np.zeros((4, 56))]*4, p)                  # next step: kick-off on 1 and 2
+  assert np.allclose(p.data.qpos[1, 2], soccer.INIT_BALL_Z) and np.allclose(p.data.qpos[2, 2], 0.5)
+  np.testing.assert_array_equal(p.data.qpos[0], before[0])
+  assert p.control.shape == (4, 224)
+  never, _ = _task(terminate_on_goal=False)                   # MultiturnTask: discount stays 1
+  never.initialize_episode(p)
+  p.data.qpos[0, 0:3] = pitch.away_goal[2]
+  never.after_step(p)
+  np.testing.assert_array_equal(never.discount(p), [1, 1, 1, 1])
+  assert never.get_reward(p)[0][0] == 1
+
+
+def test_throw_in_brings_the_ball_back(model):
+  task, pitch = _task(seed=2)
+  p = FakePhysics(model, 3)
+  task.initialize_episode(p)
+  p.data.qpos[1, 0:3] = [3.0, 8.5, 0.12]     # beyond the field rectangle in y
+  p.data.qvel[1, 0:6] = 1.0
+  task.before_step(np.zeros((3, 224)), p)
+  x, y, z = p.data.qpos[1, 0:3]
+  assert 0.7*3.0 <= x <= 0.9*3.0 and 0.7*8.5 <= y <= 0.9*8.5 and z == soccer.THROW_IN_BALL_Z
+  assert not np.any(p.data.qvel[1, 0:6])
+  assert not pitch.off_court(p.data.qpos[:, 0:3]).any()
+
+
+def test_observables_are_egocentric(model):
+  task, pitch = _task()
+  p = FakePhysics(model, 2)
+  task.initialize_episode(p)
+  q, v = p.data.qpos, p.data.qvel
+  # player 0 (home) at (1, 2), turned by 90 degrees about z; the ball 3 m along world +y
+  a = 7
+  turn = np.array([np.cos(np.pi/4), 0, 0, np.sin(np.pi/4)])
+  q[:, a:a + 3] = [1.0, 2.0, 1.05]
+  q[:, a + 3:a + 7] = soccer._quat_mul(turn, model.qpos0[a + 3:a + 7])
+  q[:, 0:3] = [1.0, 5.0, 0.3]
+  v[:, 0:3] = [0.5, 0, 0]
+  v[:, 6:9] = [0, 0.25, 0]                    # player 0 moves along world +y
+  obs = task.get_observation(p)
+  assert len(obs) == 4
+  o = obs[0]
+  mat = soccer._quat_to_mat(q[:, a + 3:a + 7])
+  want = np.einsum('bi,bij->bj', q[:, 0:3] - q[:, a:a + 3], mat)
+  np.testing.assert_allclose(o['ball_ego_position'], want)
+  # distance and height are frame independent; the ball is level with the hips minus 0.75
+  np.testing.assert_allclose(np.linalg.norm(o['ball_ego_position'], axis=1), np.hypot(3.0, 0.75))
+  np.testing.assert_allclose(o['ball_ego_linear_velocity'],
+                             np.einsum('bi,bij->bj', v[:, 0:3] - v[:, 6:9], mat))
+  np.testing.assert_allclose(o['body_height'], 1.05)
+  assert o['joints_pos'].shape == (2, 56) and o['joints_vel'].shape == (2, 56)
+  assert o['world_zaxis'].shape == (2, 3) and o['prev_action'].shape == (2, 56)
+  # naming: one teammate, two opponents, in player order
+  for name in ('teammate_0_ego_position', 'opponent_0_ego_position', 'opponent_1_ego_position',
+               'teammate_0_ego_orientation', 'opponent_1_ego_linear_velocity'):
+    assert name in o
+  assert 'teammate_1_ego_position' not in o and o['teammate_0_ego_orientation'].shape == (2, 9)
+  np.testing.assert_allclose(
+      o['opponent_0_ego_position'],
+      np.einsum('bi,bij->bj', q[:, 7 + 126:10 + 126] - q[:, a:a + 3], mat))
+  # arena features: 2-vectors use the upper-left block; the away team sees the
+  # pitch from the other end (its own goal is the away goal)
+  np.testing.assert_allclose(
+      o['team_goal_mid'], np.einsum('bi,bij->bj', pitch.home_goal[2] - q[:, a:a + 3], mat))
+  np.testing.assert_allclose(
+      o['field_front_left'],
+      np.einsum('bi,bij->bj', pitch.field[1] - q[:, a:a + 2], mat[:, :2, :2]))
+  away = obs[2]
+  b = 7 + 126
+  mat2 = soccer._quat_to_mat(q[:, b + 3:b + 7])
+  np.testing.assert_allclose(
+      away['team_goal_mid'], np.einsum('bi,bij->bj', pitch.away_goal[2] - q[:, b:b + 3], mat2))
+  np.testing.assert_allclose(
+      away['field_front_left'],
+      np.einsum('bi,bij->bj', pitch.field[0] - q[:, b:b + 2], mat2[:, :2, :2]))
+  assert list(o.keys())[:5] == ['joints_pos', 'joints_vel', 'body_height', 'world_zaxis',
+                                'prev_action']
+
+
+def test_load_argument_checks():
+  with pytest.raises(ValueError):
+    soccer.load(0)
+  with pytest.raises(ValueError):
+    soccer.load(2, walker_type=soccer.WalkerType.BOXHEAD)
+  with pytest.raises(ValueError):
+    soccer.load(2, enable_field_box=True)

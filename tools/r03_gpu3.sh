@@ -28,6 +28,7 @@ for spec in "cheetah run 8192 f64" "cheetah run 65536 f32" "cheetah run 262144 f
   set -- $spec
   timeout -k 10 400 python bench.py --domain $1 --task $2 --batch $3 --precision $4 --no-compliant-leg > $O/bench_$1_$2_b$3_$4.json 2> $O/bench_$1_$2_b$3_$4.err || exit 1
 done
+timeout -k 10 900 python bench.py --domain soccer --task 2v2 --batch 1024 --steps 10 --warmup 2 --no-compliant-leg > $O/bench_soccer_2v2_b1024_f32.json 2> $O/bench_soccer_2v2_b1024_f32.err || { echo soccer bench failed; tail -5 $O/bench_soccer_2v2_b1024_f32.err; }
 python3 - <<PY
 import json,glob
 for f in sorted(glob.glob('$O/bench_*.json')):
