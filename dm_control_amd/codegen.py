@@ -461,6 +461,16 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   ti('root_body', roots)
   ti('body_rootidx', [roots.index(int(r)) if int(r) in roots else 0
                       for r in m.body_rootid])
+  # first dof of the kinematic tree a dof belongs to: rows of M (and of the
+  # Newton Hessian while no contact couples two trees) are zero left of it --
+  # the envelope that the big-scene kernels confine their matrix loops to
+  treeroot = []
+  for i in range(m.nv):
+    d = i
+    while int(m.dof_parentid[d]) >= 0:
+      d = int(m.dof_parentid[d])
+    treeroot.append(d)
+  ti('dof_treeroot', treeroot or [0])
   # [body][word]: bit (j & 31) of word (j >> 5) set <=> dof j moves the body
   # (multi-word, so scenes with several walkers -- nv > 64 -- compile too)
   nmaskw = max(1, (m.nv + 31)//32)

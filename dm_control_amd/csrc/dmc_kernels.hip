@@ -314,6 +314,71 @@ DEV void chol_solve(real* x, const Mat& L) {
   }
 }
 
+// Envelope ("skyline") forms for big scenes (MAT_IN_WS): row i of the matrix is
+// zero left of column lo(i) -- M is block diagonal over the kinematic trees, the
+// Hessian couples two trees only where a contact does -- and a Cholesky factor
+// has no fill outside that envelope, so every loop over a row starts at lo(i).
+// The skipped terms are exact zeros: same values as the dense loops.
+struct LoTree {      // the envelope of M: the first dof of the row's kinematic tree
+  __device__ __forceinline__ int operator()(int i) const { return dof_treeroot[i]; }
+};
+struct LoArr {
+  const int* p;
+  __device__ __forceinline__ int operator()(int i) const { return p[i]; }
+};
+template <class Mat, class Lo>
+DEV void symv_env(real* y, const Mat& A, const real* x, const Lo& lo) {
+  for (int i = 0; i < NV; i++) y[i] = 0;
+  for (int i = 0; i < NV; i++)
+    for (int j = lo(i); j <= i; j++) {
+      const real a = A.get(tri(i, j));
+      y[i] += a*x[j];
+      if (j != i) y[j] += a*x[i];
+    }
+}
+template <class Mat, class Lo>
+DEV int chol_factor_env(const Mat& A, const Lo& lo) {
+  int nbad = 0;
+  for (int j = 0; j < NV; j++) {
+    real rowj[NVX];
+    const int lj = lo(j);
+    real s = A.get(tri(j, j));
+    for (int k = lj; k < j; k++) { rowj[k] = A.get(tri(j, k)); s -= rowj[k]*rowj[k]; }
+    if (!(s >= DMC_MINVAL)) { s = DMC_MINVAL; nbad++; }
+    const real inv = rsqrt_(s);
+    A.set(tri(j, j), inv);
+    for (int i = j + 1; i < NV; i++) {
+      const int li = lo(i);
+      if (li > j) continue;
+      real t = A.get(tri(i, j));
+      for (int k = li > lj ? li : lj; k < j; k++) t -= A.get(tri(i, k))*rowj[k];
+      A.set(tri(i, j), t*inv);
+    }
+  }
+  return nbad;
+}
+template <class Mat, class Lo>
+DEV void chol_solve_env(real* x, const Mat& L, const Lo& lo) {
+  for (int i = 0; i < NV; i++) {
+    real s = x[i];
+    for (int k = lo(i); k < i; k++) s -= L.get(tri(i, k))*x[k];
+    x[i] = s*L.get(tri(i, i));
+  }
+  for (int i = NV - 1; i >= 0; i--) {     // row i of L pushes x[i] into the earlier entries
+    const real xi = x[i]*L.get(tri(i, i));
+    x[i] = xi;
+    for (int k = lo(i); k < i; k++) x[k] -= L.get(tri(i, k))*xi;
+  }
+}
+// dst = src inside dst's envelope `lo`; src is zero left of `slo`
+template <class Mat, class Lo, class SLo>
+DEV void copy_env(const Mat& dst, const Mat& src, const Lo& lo, const SLo& slo) {
+  for (int i = 0; i < NV; i++) {
+    const int si = slo(i);
+    for (int j = lo(i); j <= i; j++) dst.set(tri(i, j), j >= si ? src.get(tri(i, j)) : R(0));
+  }
+}
+
 // ---------------------------------------------------------------------------
 // per-lane working set of one environment
 // ---------------------------------------------------------------------------
@@ -340,6 +405,7 @@ struct Env {
 #endif
   int ncon, nefc, nefc_limit, iters;
   int nmerged;     // pyramid edge pairs stored as one row (PLANAR_MERGE)
+  int hlo[MAT_IN_WS ? NVX : 1];   // big scenes: envelope of the Newton Hessian (first column per row)
   unsigned warn;
 };
 
@@ -657,8 +723,13 @@ DEV void crb_factor(Env& E, const Work& W) {
     if (body_parentid[i] > 0)
       DMC_UNROLL
       for (int k = 0; k < 10; k++) crb[10*body_parentid[i] + k] += crb[10*i + k];
-  DMC_UNROLL
-  for (int i = 0; i < NM; i++) M.set(i, 0);
+  if (MAT_IN_WS) {
+    for (int i = 0; i < NV; i++)
+      for (int j = dof_treeroot[i]; j <= i; j++) M.set(tri(i, j), 0);
+  } else {
+    DMC_UNROLL
+    for (int i = 0; i < NM; i++) M.set(i, 0);
+  }
   DMC_UNROLL
   for (int i = 0; i < NV; i++) {
     real buf[6];
@@ -670,6 +741,11 @@ DEV void crb_factor(Env& E, const Work& W) {
         const int j = dof_anc[i*MAXCHAIN + a];
         M.set(tri(i, j), dot6(E.cdof + 6*j, buf));
       }
+  }
+  if (MAT_IN_WS) {
+    copy_env(L, M, LoTree{}, LoTree{});
+    if (chol_factor_env(L, LoTree{})) E.warn |= WARN_INERTIA;
+    return;
   }
   DMC_UNROLL
   for (int i = 0; i < NM; i++) L.set(i, M.get(i));
@@ -808,7 +884,8 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
   }
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qacc_smooth[i] = E.qfrc_smooth[i];
-  chol_solve(E.qacc_smooth, Mats::L(E, W));
+  if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
+  else chol_solve(E.qacc_smooth, Mats::L(E, W));
 }
 
 DEV void subtree_vel(Env& E) {
@@ -1678,9 +1755,25 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
   const LaneMat F = Mats::L(E, W);
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
-  symv(Ma, M, E.qacc);
-  DMC_UNROLL
-  for (int i = 0; i < NM; i++) H.set(i, M.get(i));
+  if (MAT_IN_WS) {
+    // envelope of the Hessian: M's, widened for the dofs of every constraint row
+    // to the row's first dof (a contact between two trees couples their blocks)
+    for (int i = 0; i < NV; i++) E.hlo[i] = dof_treeroot[i];
+    for_rows(W, nefc, [&](auto rec) {
+      int first = NV;
+      for (int j = 0; j < NV; j++)
+        if (rec.get(j) != 0) {
+          if (first == NV) first = j;
+          if (first < E.hlo[j]) E.hlo[j] = first;
+        }
+    });
+    symv_env(Ma, M, E.qacc, LoTree{});
+    copy_env(H, M, LoArr{E.hlo}, LoTree{});
+  } else {
+    symv(Ma, M, E.qacc);
+    DMC_UNROLL
+    for (int i = 0; i < NM; i++) H.set(i, M.get(i));
+  }
   real improvement = 0, alpha_prev = 0;
   int iter = 0;
   for (;; iter++) {
@@ -1711,11 +1804,22 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
       if (now != was) {
         changed = true;
         const real Ds = now ? D : -D;
-        DMC_UNROLL
-        for (int j = 0; j < NV; j++) {
-          const real s = Ds*row[j];
+        if (MAT_IN_WS) {               // only the row's non-zero dofs touch H
+          int first = NV;
+          for (int j = 0; j < NV; j++) {
+            if (row[j] == 0) continue;
+            if (first == NV) first = j;
+            const real s = Ds*row[j];
+            for (int k = first; k <= j; k++)
+              if (row[k] != 0) H.set(tri(j, k), H.get(tri(j, k)) + s*row[k]);
+          }
+        } else {
           DMC_UNROLL
-          for (int k = 0; k <= j; k++) H.set(tri(j, k), H.get(tri(j, k)) + s*row[k]);
+          for (int j = 0; j < NV; j++) {
+            const real s = Ds*row[j];
+            DMC_UNROLL
+            for (int k = 0; k <= j; k++) H.set(tri(j, k), H.get(tri(j, k)) + s*row[k]);
+          }
         }
       }
     });
@@ -1733,11 +1837,17 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
     DMC_UNROLL
-    for (int i = 0; i < NM; i++) F.set(i, H.get(i));
-    chol_factor(F);
-    DMC_UNROLL
     for (int i = 0; i < NV; i++) search[i] = -grad[i];
-    chol_solve(search, F);
+    if (MAT_IN_WS) {
+      copy_env(F, H, LoArr{E.hlo}, LoArr{E.hlo});
+      chol_factor_env(F, LoArr{E.hlo});
+      chol_solve_env(search, F, LoArr{E.hlo});
+    } else {
+      DMC_UNROLL
+      for (int i = 0; i < NM; i++) F.set(i, H.get(i));
+      chol_factor(F);
+      chol_solve(search, F);
+    }
     SPROF(1);
     real sn = 0;
     DMC_UNROLL
@@ -1746,7 +1856,8 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
     alpha_prev = 0;               // nothing pending if one of the exits below is taken
     if (sn < DMC_MINVAL) break;
     const real gtol = tol*R(0.01)*sn/scale;
-    symv(Mv, M, search);
+    if (MAT_IN_WS) symv_env(Mv, M, search, LoTree{});
+    else symv(Mv, M, search);
     real q1 = 0, q2 = 0;
     DMC_UNROLL
     for (int i = 0; i < NV; i++) {
@@ -1944,7 +2055,8 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
     real Ma[NVX], cw = 0, cs = 0;
     if (try_warm) {
-      symv(Ma, Mats::M(E, W), E.warm);
+      if (MAT_IN_WS) symv_env(Ma, Mats::M(E, W), E.warm, LoTree{});
+      else symv(Ma, Mats::M(E, W), E.warm);
       DMC_UNROLL
       for (int i = 0; i < NV; i++)
         cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
@@ -2084,15 +2196,23 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
       real Areg[MAT_REGS];
       const auto M = Mats::M(E, W);
       const LaneMat A = Mats::local(Areg, W, MAT_A);
-      DMC_UNROLL
-      for (int i = 0; i < NM; i++) A.set(i, M.get(i));
+      if (MAT_IN_WS) copy_env(A, M, LoTree{}, LoTree{});
+      else {
+        DMC_UNROLL
+        for (int i = 0; i < NM; i++) A.set(i, M.get(i));
+      }
       DMC_UNROLL
       for (int i = 0; i < NV; i++) {
         A.set(tri(i, i), A.get(tri(i, i)) + h*R(dof_damping[i]));
         qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
       }
-      chol_factor(A);
-      chol_solve(qacc, A);
+      if (MAT_IN_WS) {
+        chol_factor_env(A, LoTree{});
+        chol_solve_env(qacc, A, LoTree{});
+      } else {
+        chol_factor(A);
+        chol_solve(qacc, A);
+      }
     } else {
       DMC_UNROLL
       for (int i = 0; i < NV; i++) qacc[i] = E.qacc[i];
