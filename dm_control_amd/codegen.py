@@ -478,6 +478,14 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   w('static __device__ constexpr unsigned body_dofmask[] = {%s};'
     % ', '.join('%du' % ((b >> (32*k)) & 0xffffffff)
                 for b in masks for k in range(nmaskw)))
+  # kinematic trees (roots = children of the world): per-step bounding spheres
+  # of the trees let big scenes skip whole blocks of walker-walker pairs
+  tree_of_body = [-1 if int(r) == 0 else roots.index(int(r)) for r in m.body_rootid]
+  tree_of_body[0] = -1
+  ci('NTREE', len(roots) if m.nbody > 1 else 0)
+  ti('geom_tree', [tree_of_body[int(b)] for b in m.geom_bodyid] or [-1])
+  ti('pair_tree1', [tree_of_body[int(m.geom_bodyid[p[0]])] for p in pairs] or [-1])
+  ti('pair_tree2', [tree_of_body[int(m.geom_bodyid[p[1]])] for p in pairs] or [-1])
   ti('pair_b1', [int(m.geom_bodyid[p[0]]) for p in pairs])
   ti('pair_b2', [int(m.geom_bodyid[p[1]]) for p in pairs])
   ci('MAXCHAIN', maxchain)

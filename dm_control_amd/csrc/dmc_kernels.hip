@@ -414,7 +414,10 @@ struct Env {
 // hits its own bank, conflict-free for any per-lane row index); records beyond
 // that spill to the HBM workspace with the same [word][env] layout.
 // Contact records ([pos3 n3 tangent-hint3 dist pair]) use the same two tiers.
-constexpr int RW = NV + 4;
+// (big scenes, MAT_IN_WS: + the span [lo, hi] of the row's non-zero dofs; the
+// passes over a row then touch only that span -- a joint-limit row is one dof, a
+// foot-ground contact the 62 dofs of one walker, not the 254 of the pitch)
+constexpr int RW = NV + 4 + (MAT_IN_WS ? 2 : 0);
 constexpr int CW = 11;
 #ifndef DMC_LDS_BUDGET
 #define DMC_LDS_BUDGET (128*1024)
@@ -432,7 +435,11 @@ constexpr int LDS_ROWS = LDS_ROWS_FIT < NEFC_MAX ? LDS_ROWS_FIT : NEFC_MAX;
 static_assert(LDS_CONS >= 0 && LDS_ROWS >= 0, "LDS budget arithmetic");
 constexpr int GLB_ROWS = NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 0;
 constexpr int GLB_CONS = NCON_MAX - LDS_CONS > 0 ? NCON_MAX - LDS_CONS : 0;
-enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3 };
+enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3,
+       ROW_LO = NV + 4, ROW_HI = NV + 5 };
+// span of a row record: compile-time [0, NV) unless the record carries one
+template <class Rec> DEV int row_lo(const Rec& rec) { return MAT_IN_WS ? (int)rec.get(ROW_LO) : 0; }
+template <class Rec> DEV int row_hi(const Rec& rec) { return MAT_IN_WS ? (int)rec.get(ROW_HI) : NV - 1; }
 
 struct LdsRow {
   real* p;
@@ -962,8 +969,17 @@ template <class Row>
 DEV void write_row(const Row& rec, const Env& E, const real* row, real pm,
                    real K, real B, real imp, real Rrow) {
   real vel = 0;
-  DMC_UNROLL
-  for (int j = 0; j < NV; j++) { rec.set(j, row[j]); vel += row[j]*E.qvel[j]; }
+  if (MAT_IN_WS) {
+    int lo = NV, hi = -1;
+    for (int j = 0; j < NV; j++)
+      if (row[j] != 0) { if (lo == NV) lo = j; hi = j; }
+    if (hi < 0) lo = hi = 0;
+    for (int j = lo; j <= hi; j++) { rec.set(j, row[j]); vel += row[j]*E.qvel[j]; }
+    rec.set(ROW_LO, (real)lo); rec.set(ROW_HI, (real)hi);
+  } else {
+    DMC_UNROLL
+    for (int j = 0; j < NV; j++) { rec.set(j, row[j]); vel += row[j]*E.qvel[j]; }
+  }
   rec.set(ROW_AREF, -B*vel - K*imp*pm);
   rec.set(ROW_D, R(1)/(Rrow < DMC_MINVAL ? DMC_MINVAL : Rrow));
 }
@@ -1554,8 +1570,43 @@ DEV void detect_contacts(Env& E, const Work& W) {
   real Garr[MAT_IN_WS ? 1 : NGEOM*12];
   const auto G = PoseSrc<MAT_IN_WS>::make(W, Garr);
   geom_poses(E, G);
+  // Big scenes: one bounding sphere per kinematic tree (centre: the tree's
+  // centre of mass), so the blocks of pairs between two walkers that are nowhere
+  // near each other are skipped without touching their geoms.  Conservative:
+  // a skipped pair's own bounding-sphere test would have rejected it.
+  constexpr int NTREEX = NTREE > 0 ? NTREE : 1;
+  real tcen[MAT_IN_WS ? NTREEX*3 : 1], trad[MAT_IN_WS ? NTREEX : 1];
+  if (MAT_IN_WS && NTREE > 1) {
+    for (int t = 0; t < NTREE; t++) {
+      trad[t] = 0;
+      for (int k = 0; k < 3; k++) tcen[3*t + k] = E.subtree_com[3*root_body[t] + k];
+    }
+    for (int g = 0; g < NGEOM; g++) {
+      const int t = geom_tree[g];
+      if (t < 0) continue;
+      real d2 = 0;
+      for (int k = 0; k < 3; k++) {
+        const real d = G.get(12*g + k) - tcen[3*t + k];
+        d2 += d*d;
+      }
+      const real reach = sqrt(d2) + R(geom_rbound[g]);
+      if (reach > trad[t]) trad[t] = reach;
+    }
+  }
   DMC_UNROLL_PAIRS
   for (int p = 0; p < NPAIR; p++) {
+    if (MAT_IN_WS && NTREE > 1) {
+      const int t1 = pair_tree1[p], t2 = pair_tree2[p];
+      if (t1 >= 0 && t2 >= 0 && t1 != t2) {
+        real d2 = 0;
+        for (int k = 0; k < 3; k++) {
+          const real d = tcen[3*t1 + k] - tcen[3*t2 + k];
+          d2 += d*d;
+        }
+        const real reach = trad[t1] + trad[t2] + R(pair_margin[p]);
+        if (d2 > reach*reach) continue;
+      }
+    }
     RawCon rc[4];
     const int mask = collide_pair(G, p, rc);
     if (mask == 0) continue;
@@ -1760,12 +1811,10 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
     // to the row's first dof (a contact between two trees couples their blocks)
     for (int i = 0; i < NV; i++) E.hlo[i] = dof_treeroot[i];
     for_rows(W, nefc, [&](auto rec) {
-      int first = NV;
-      for (int j = 0; j < NV; j++)
-        if (rec.get(j) != 0) {
-          if (first == NV) first = j;
-          if (first < E.hlo[j]) E.hlo[j] = first;
-        }
+      const int lo = row_lo(rec), hi = row_hi(rec);
+      if (hi == lo) return;                    // one dof (a joint limit): diagonal only
+      for (int j = lo; j <= hi; j++)
+        if (rec.get(j) != 0 && lo < E.hlo[j]) E.hlo[j] = lo;
     });
     symv_env(Ma, M, E.qacc, LoTree{});
     copy_env(H, M, LoArr{E.hlo}, LoTree{});
@@ -1784,8 +1833,9 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
       real jar = rec.get(ROW_JAR);
       const real jv = rec.get(ROW_JV), D = rec.get(ROW_D);
       real row[NVX];
+      const int jlo = row_lo(rec), jhi = row_hi(rec);
       DMC_UNROLL
-      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+      for (int j = jlo; j <= jhi; j++) row[j] = rec.get(j);
       bool was = false;                 // is this row's term in H?
       if (iter > 0) {
         was = jar < 0;
@@ -1799,18 +1849,16 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
       if (now) {
         const real f = -D*jar;
         DMC_UNROLL
-        for (int j = 0; j < NV; j++) E.qfrc_constraint[j] += row[j]*f;
+        for (int j = jlo; j <= jhi; j++) E.qfrc_constraint[j] += row[j]*f;
       }
       if (now != was) {
         changed = true;
         const real Ds = now ? D : -D;
         if (MAT_IN_WS) {               // only the row's non-zero dofs touch H
-          int first = NV;
-          for (int j = 0; j < NV; j++) {
+          for (int j = jlo; j <= jhi; j++) {
             if (row[j] == 0) continue;
-            if (first == NV) first = j;
             const real s = Ds*row[j];
-            for (int k = first; k <= j; k++)
+            for (int k = jlo; k <= j; k++)
               if (row[k] != 0) H.set(tri(j, k), H.get(tri(j, k)) + s*row[k]);
           }
         } else {
@@ -1872,12 +1920,13 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
       real d0 = q1, d1 = 2*q2;
       for_rows(W, nefc, [&](auto rec) {
         real row[NVX];
+        const int jlo = row_lo(rec), jhi = row_hi(rec);
         DMC_UNROLL
-        for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+        for (int j = jlo; j <= jhi; j++) row[j] = rec.get(j);
         const real x0 = rec.get(ROW_JAR), D = rec.get(ROW_D);
         real sacc = 0;
         DMC_UNROLL
-        for (int j = 0; j < NV; j++) sacc += row[j]*search[j];
+        for (int j = jlo; j <= jhi; j++) sacc += row[j]*search[j];
         rec.set(ROW_JV, sacc);
         const real Dv = D*sacc;
         if (x0 < 0) { d0 += Dv*x0; d1 += Dv*sacc; }
@@ -2063,12 +2112,13 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     }
     for_rows(W, E.nefc, [&](auto rec) {
       real row[NVX];
+      const int jlo = row_lo(rec), jhi = row_hi(rec);
       DMC_UNROLL
-      for (int j = 0; j < NV; j++) row[j] = rec.get(j);
+      for (int j = jlo; j <= jhi; j++) row[j] = rec.get(j);
       const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
       real jw = 0, js = 0;
       DMC_UNROLL
-      for (int j = 0; j < NV; j++) { jw += row[j]*E.warm[j]; js += row[j]*E.qacc_smooth[j]; }
+      for (int j = jlo; j <= jhi; j++) { jw += row[j]*E.warm[j]; js += row[j]*E.qacc_smooth[j]; }
       jw -= aref; js -= aref;
       if (jw < 0) cw += R(0.5)*D*jw*jw;
       if (js < 0) cs += R(0.5)*D*js*js;

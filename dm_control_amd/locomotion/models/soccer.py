@@ -103,6 +103,15 @@ def build(num_walkers=1, with_ball=True, pitch_size=PITCH_SIZE,
                                  ('away_goal', -1, lx - goal_size[0] - field_box_offset)):
       for name, fromto, r in goal_frame_capsules((x, 0.0, goal_size[2]), goal_size, direction):
         m.node(world, 'geom', name='%s/%s' % (prefix, name), fromto=fromto, size=(r,), **posts)
+  if walker_positions is None:
+    walker_positions = default_positions(num_walkers)
+  for i in range(num_walkers):
+    cmu_humanoid.add_walker(root, world, actuator, contact, prefix='walker%d/' % i,
+                            pos=tuple(walker_positions[i]),
+                            contype=0 if disable_walker_contacts else None)
+  # The ball comes LAST in the kinematic order: a ball-walker contact then widens
+  # the envelope of the ball's six Hessian rows only, not that of the walker's 62
+  # (csrc/dmc_kernels.hip, envelope Cholesky of big scenes).
   if with_ball:
     prm = BALL if ball is None else ball
     body = m.node(world, 'body', name='ball', pos=(0, 0, prm['radius'] + 0.01))
@@ -110,10 +119,4 @@ def build(num_walkers=1, with_ball=True, pitch_size=PITCH_SIZE,
     m.node(body, 'geom', name='ball', type='sphere', size=(prm['radius'],), condim=6,
            priority=1, mass=prm['mass'], friction=prm['friction'],
            solref=(0.02, prm['damp_ratio']), solimp=(0.9, 0.95, 0.001))
-  if walker_positions is None:
-    walker_positions = default_positions(num_walkers)
-  for i in range(num_walkers):
-    cmu_humanoid.add_walker(root, world, actuator, contact, prefix='walker%d/' % i,
-                            pos=tuple(walker_positions[i]),
-                            contype=0 if disable_walker_contacts else None)
   return m.to_string(root)

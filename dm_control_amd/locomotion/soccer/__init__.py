@@ -145,11 +145,20 @@ class Task(control.Task):
     self._prev_action = None
 
   # -- layout of the scene's state vectors ---------------------------------------
+  # (walkers first, the ball last: locomotion/models/soccer.py)
   def _walker_q(self, k):
-    return 7 + NQ_WALKER*k
+    return NQ_WALKER*k
 
   def _walker_v(self, k):
-    return 6 + NV_WALKER*k
+    return NV_WALKER*k
+
+  @property
+  def _ball_q(self):
+    return NQ_WALKER*self.num_players
+
+  @property
+  def _ball_v(self):
+    return NV_WALKER*self.num_players
 
   # -- episode -------------------------------------------------------------------
   def _draw_kickoff(self, rs):
@@ -175,8 +184,9 @@ class Task(control.Task):
       pts, heading = self._draw_kickoff(self._random)
       qpos[e] = m.qpos0
       qvel[e] = 0
-      qpos[e, 0:2] = pts[0]
-      qpos[e, 2] = INIT_BALL_Z
+      bq = self._ball_q
+      qpos[e, bq:bq + 2] = pts[0]
+      qpos[e, bq + 2] = INIT_BALL_Z
       for k in range(self.num_players):
         a = self._walker_q(k)
         qpos[e, a:a + 2] = pts[1 + k]
@@ -201,7 +211,8 @@ class Task(control.Task):
     if self._scored is not None and (self._scored >= 0).any():
       self.initialize_episode(physics, only=self._scored >= 0)
       self._scored[:] = -1
-    ball = np.atleast_2d(np.asarray(physics.data.qpos, np.float64))[:, :3]
+    ball = np.atleast_2d(np.asarray(physics.data.qpos, np.float64))[
+        :, self._ball_q:self._ball_q + 3]
     out = self.pitch.off_court(ball)
     if out.any():
       self._throw_in(physics, out)
@@ -212,15 +223,17 @@ class Task(control.Task):
     qvel = np.atleast_2d(np.asarray(physics.data.qvel, np.float64)).copy()
     for e in np.nonzero(mask)[0]:
       shrink = self._random.uniform([0.7, 0.7], [0.9, 0.9])
-      qpos[e, 0:2] *= shrink
-      qpos[e, 2] = THROW_IN_BALL_Z
-      qpos[e, 3:7] = [1, 0, 0, 0]
-      qvel[e, 0:6] = 0
+      bq, bv = self._ball_q, self._ball_v
+      qpos[e, bq:bq + 2] *= shrink
+      qpos[e, bq + 2] = THROW_IN_BALL_Z
+      qpos[e, bq + 3:bq + 7] = [1, 0, 0, 0]
+      qvel[e, bv:bv + 6] = 0
     physics.set_state(np.concatenate([qpos, qvel], axis=1) if physics.batch_size
                       else np.concatenate([qpos[0], qvel[0]]))
 
   def after_step(self, physics):
-    ball = np.atleast_2d(np.asarray(physics.data.qpos, np.float64))[:, :3]
+    ball = np.atleast_2d(np.asarray(physics.data.qpos, np.float64))[
+        :, self._ball_q:self._ball_q + 3]
     scored = np.full(len(ball), -1)
     scored[self.pitch.in_goal(ball, self.pitch.home_goal)] = 1    # away team scores
     scored[self.pitch.in_goal(ball, self.pitch.away_goal)] = 0
@@ -262,8 +275,10 @@ class Task(control.Task):
     qpos = np.atleast_2d(np.asarray(physics.data.qpos, np.float64))
     qvel = np.atleast_2d(np.asarray(physics.data.qvel, np.float64))
     n = len(qpos)
-    ball_pos, ball_lin = qpos[:, 0:3], qvel[:, 0:3]
-    ball_ang = _ego(qvel[:, 3:6], np.swapaxes(_quat_to_mat(qpos[:, 3:7]), -1, -2))  # local -> world
+    bq, bv = self._ball_q, self._ball_v
+    ball_pos, ball_lin = qpos[:, bq:bq + 3], qvel[:, bv:bv + 3]
+    ball_ang = _ego(qvel[:, bv + 3:bv + 6],
+                    np.swapaxes(_quat_to_mat(qpos[:, bq + 3:bq + 7]), -1, -2))  # local -> world
     root_pos, root_mat, root_lin = [], [], []
     for k in range(self.num_players):
       a, v = self._walker_q(k), self._walker_v(k)

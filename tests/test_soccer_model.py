@@ -223,6 +223,7 @@ def _teacher_forced(m, hb, qpos, qvel, steps, rs, W):
     d.qvel[:] = qvel[i]
     d.step1()
   errs, rows = [], 0
+  _teacher_forced.max_ncon = 0
   for _ in range(steps):
     oq = np.array([d.qpos.copy() for d in datas])
     ov = np.array([d.qvel.copy() for d in datas])
@@ -235,6 +236,7 @@ def _teacher_forced(m, hb, qpos, qvel, steps, rs, W):
     for i, d in enumerate(datas):
       d.ctrl[:] = ctrl[i]
       rows += d.nefc
+      _teacher_forced.max_ncon = max(_teacher_forced.max_ncon, d.ncon)
       d.physics_step()
     nq = np.array([d.qpos.copy() for d in datas])
     nv = np.array([d.qvel.copy() for d in datas])
@@ -316,7 +318,7 @@ def _pitch_states(m, nenv, rs):
   qvel = 0.2*rs.randn(nenv, m.nv)
   for e in range(nenv):
     for k in range(4):
-      a = 7 + 63*k
+      a = 63*k                    # walkers first, the ball last
       qpos[e, a + 7:a + 63] += 0.15*rs.randn(56)
       if (e + k) % 3 == 2:        # lying on the back / side
         qpos[e, a + 2] = 0.25
@@ -324,9 +326,9 @@ def _pitch_states(m, nenv, rs):
         qpos[e, a + 3:a + 7] /= np.linalg.norm(qpos[e, a + 3:a + 7])
       else:                       # standing, feet at / slightly in the ground
         qpos[e, a + 2] = rs.uniform(0.84, 0.92)   # (feet reach the ground below 0.93)
-    foot = qpos[e, 7:9]
-    qpos[e, 0:2] = foot + (rs.uniform(-0.25, 0.25, 2) if e % 2 == 0 else [3.0, 1.0])
-    qpos[e, 2] = 0.115 if e % 2 == 0 else 0.6
+    foot = qpos[e, 0:2]
+    qpos[e, 252:254] = foot + (rs.uniform(-0.25, 0.25, 2) if e % 2 == 0 else [3.0, 1.0])
+    qpos[e, 254] = 0.115 if e % 2 == 0 else 0.6
   return qpos, qvel
 
 
@@ -345,10 +347,9 @@ def test_single_walker_fp64_at_full_contact_capacity():
   qpos[6:, 2] = 0.2
   qpos[6:, 3:7] = [1, 0, 0, 0]
   e, rows = _teacher_forced(m, hb, qpos, qvel, 8, rs, W)
-  stats = hb.read(W.FIELD_STATS)
   print('OBSERVED soccer walker f64 rolled, full capacity: max %.2e, ncon up to %d' % (
-      e.max(), stats[0].max()))
-  assert stats[0].max() > 4 and rows > 12*8*10
+      e.max(), _teacher_forced.max_ncon))
+  assert _teacher_forced.max_ncon > 4 and rows > 12*8*10
   assert not hb.read(W.FIELD_WARN).any()
   assert e.max() <= 1e-9, e.max()
   hb.free()
@@ -370,15 +371,14 @@ def test_two_by_two_pitch_on_device_matches_oracle(quiet):
   nenv = 6
   qpos, qvel = _pitch_states(m, nenv, rs)
   if not quiet:                   # two players into each other
-    qpos[:, 7 + 63:7 + 63 + 2] = qpos[:, 7:9] + [0.25, 0.1]
+    qpos[:, 63:65] = qpos[:, 0:2] + [0.25, 0.1]
   hm = W.HipModel(build.build_model(m, 0, 'f64', ncon_max=64, mode='rolled'))
   hb = W.HipBatch(hm, nenv)
   e, rows = _teacher_forced(m, hb, qpos, qvel, 5, np.random.RandomState(1), W)
-  stats = hb.read(W.FIELD_STATS)
-  print('OBSERVED 2v2 pitch f64 (quiet=%s): per-step max %.2e; ncon up to %d, nefc up to %d'
-        % (quiet, e.max(), stats[0].max(), stats[1].max()))
+  print('OBSERVED 2v2 pitch f64 (quiet=%s): per-step max %.2e; ncon up to %d, %d rows in all'
+        % (quiet, e.max(), _teacher_forced.max_ncon, rows))
   assert not hb.read(W.FIELD_WARN).any()
-  assert stats[0].max() >= 6 and rows > nenv*5*40
+  assert _teacher_forced.max_ncon >= 30 and rows > nenv*5*250
   assert e.max() <= 1e-9, e.max()
   hb.free()
   hm32 = W.HipModel(build.build_model(m, 0, 'f32', ncon_max=64, mode='rolled'))
@@ -411,6 +411,6 @@ def test_soccer_environment_plays():
       assert np.isfinite(value).all(), key
   assert obs['ball_ego_position'].shape == (48, 3)
   assert not np.asarray(env.physics.data.warning_mask).any()
-  z = np.asarray(env.physics.data.qpos)[:, [7 + 63*k + 2 for k in range(4)]]
+  z = np.asarray(env.physics.data.qpos)[:, [63*k + 2 for k in range(4)]]
   assert (z > 0.05).all() and (z < 1.6).all()
   env.physics.free()

@@ -78,16 +78,16 @@ def test_kickoff_keeps_everyone_apart_and_inside_the_spawn_range(model):
   task.initialize_episode(p)
   q = p.data.qpos
   span = np.array(pitch.size)*soccer.SPAWN_RATIO
-  pts = [q[:, 0:2]] + [q[:, 7 + 63*k:9 + 63*k] for k in range(4)]
+  pts = [q[:, 252:254]] + [q[:, 63*k:63*k + 2] for k in range(4)]
   for a in range(5):
     assert np.all(np.abs(pts[a]) <= span)
     for b in range(a):
       assert np.all(np.linalg.norm(pts[a] - pts[b], axis=1) > 1.0)
-  np.testing.assert_allclose(q[:, 2], soccer.INIT_BALL_Z)
+  np.testing.assert_allclose(q[:, 254], soccer.INIT_BALL_Z)
   for k in range(4):          # upright: the walker's up axis stays the world z axis
-    quat = q[:, 10 + 63*k:14 + 63*k]
+    quat = q[:, 3 + 63*k:7 + 63*k]
     np.testing.assert_allclose(np.linalg.norm(quat, axis=1), 1.0)
-    up0 = soccer._quat_to_mat(model.qpos0[None, 10 + 63*k:14 + 63*k])[0]
+    up0 = soccer._quat_to_mat(model.qpos0[None, 3 + 63*k:7 + 63*k])[0]
     up = soccer._quat_to_mat(quat)
     np.testing.assert_allclose(up[:, 2, :] @ up0[2, :], 1.0, atol=1e-12)
   assert not np.any(p.data.qvel)
@@ -97,9 +97,9 @@ def test_goals_rewards_discount_and_restart(model):
   task, pitch = _task(seed=1)
   p = FakePhysics(model, 4)
   task.initialize_episode(p)
-  p.data.qpos[1, 0:3] = pitch.away_goal[2]              # home team scores on pitch 1
-  p.data.qpos[2, 0:3] = pitch.home_goal[2] + [0.1, -1.0, 0.2]   # away scores on pitch 2
-  p.data.qpos[3, 0:3] = pitch.away_goal[2] + [0, 0, 0.7]  # over the crossbar: no goal
+  p.data.qpos[1, 252:255] = pitch.away_goal[2]              # home team scores on pitch 1
+  p.data.qpos[2, 252:255] = pitch.home_goal[2] + [0.1, -1.0, 0.2]   # away scores on pitch 2
+  p.data.qpos[3, 252:255] = pitch.away_goal[2] + [0, 0, 0.7]  # over the crossbar: no goal
   task.after_step(p)
   rew = task.get_reward(p)
   assert len(rew) == 4 and rew[0].dtype == np.float32
@@ -110,12 +110,12 @@ def test_goals_rewards_discount_and_restart(model):
   assert task.get_termination(p) is None
   before = p.data.qpos.copy()
   task.before_step([np.zeros((4, 56))]*4, p)                  # next step: kick-off on 1 and 2
-  assert np.allclose(p.data.qpos[1, 2], soccer.INIT_BALL_Z) and np.allclose(p.data.qpos[2, 2], 0.5)
+  assert np.allclose(p.data.qpos[1, 254], soccer.INIT_BALL_Z) and np.allclose(p.data.qpos[2, 254], 0.5)
   np.testing.assert_array_equal(p.data.qpos[0], before[0])
   assert p.control.shape == (4, 224)
   never, _ = _task(terminate_on_goal=False)                   # MultiturnTask: discount stays 1
   never.initialize_episode(p)
-  p.data.qpos[0, 0:3] = pitch.away_goal[2]
+  p.data.qpos[0, 252:255] = pitch.away_goal[2]
   never.after_step(p)
   np.testing.assert_array_equal(never.discount(p), [1, 1, 1, 1])
   assert never.get_reward(p)[0][0] == 1
@@ -125,13 +125,13 @@ def test_throw_in_brings_the_ball_back(model):
   task, pitch = _task(seed=2)
   p = FakePhysics(model, 3)
   task.initialize_episode(p)
-  p.data.qpos[1, 0:3] = [3.0, 8.5, 0.12]     # beyond the field rectangle in y
-  p.data.qvel[1, 0:6] = 1.0
+  p.data.qpos[1, 252:255] = [3.0, 8.5, 0.12]     # beyond the field rectangle in y
+  p.data.qvel[1, 248:254] = 1.0
   task.before_step(np.zeros((3, 224)), p)
-  x, y, z = p.data.qpos[1, 0:3]
+  x, y, z = p.data.qpos[1, 252:255]
   assert 0.7*3.0 <= x <= 0.9*3.0 and 0.7*8.5 <= y <= 0.9*8.5 and z == soccer.THROW_IN_BALL_Z
-  assert not np.any(p.data.qvel[1, 0:6])
-  assert not pitch.off_court(p.data.qpos[:, 0:3]).any()
+  assert not np.any(p.data.qvel[1, 248:254])
+  assert not pitch.off_court(p.data.qpos[:, 252:255]).any()
 
 
 def test_observables_are_egocentric(model):
@@ -140,23 +140,23 @@ def test_observables_are_egocentric(model):
   task.initialize_episode(p)
   q, v = p.data.qpos, p.data.qvel
   # player 0 (home) at (1, 2), turned by 90 degrees about z; the ball 3 m along world +y
-  a = 7
+  a = 0
   turn = np.array([np.cos(np.pi/4), 0, 0, np.sin(np.pi/4)])
   q[:, a:a + 3] = [1.0, 2.0, 1.05]
   q[:, a + 3:a + 7] = soccer._quat_mul(turn, model.qpos0[a + 3:a + 7])
-  q[:, 0:3] = [1.0, 5.0, 0.3]
-  v[:, 0:3] = [0.5, 0, 0]
-  v[:, 6:9] = [0, 0.25, 0]                    # player 0 moves along world +y
+  q[:, 252:255] = [1.0, 5.0, 0.3]
+  v[:, 248:251] = [0.5, 0, 0]
+  v[:, 0:3] = [0, 0.25, 0]                    # player 0 moves along world +y
   obs = task.get_observation(p)
   assert len(obs) == 4
   o = obs[0]
   mat = soccer._quat_to_mat(q[:, a + 3:a + 7])
-  want = np.einsum('bi,bij->bj', q[:, 0:3] - q[:, a:a + 3], mat)
+  want = np.einsum('bi,bij->bj', q[:, 252:255] - q[:, a:a + 3], mat)
   np.testing.assert_allclose(o['ball_ego_position'], want)
   # distance and height are frame independent; the ball is level with the hips minus 0.75
   np.testing.assert_allclose(np.linalg.norm(o['ball_ego_position'], axis=1), np.hypot(3.0, 0.75))
   np.testing.assert_allclose(o['ball_ego_linear_velocity'],
-                             np.einsum('bi,bij->bj', v[:, 0:3] - v[:, 6:9], mat))
+                             np.einsum('bi,bij->bj', v[:, 248:251] - v[:, 0:3], mat))
   np.testing.assert_allclose(o['body_height'], 1.05)
   assert o['joints_pos'].shape == (2, 56) and o['joints_vel'].shape == (2, 56)
   assert o['world_zaxis'].shape == (2, 3) and o['prev_action'].shape == (2, 56)
@@ -167,7 +167,7 @@ def test_observables_are_egocentric(model):
   assert 'teammate_1_ego_position' not in o and o['teammate_0_ego_orientation'].shape == (2, 9)
   np.testing.assert_allclose(
       o['opponent_0_ego_position'],
-      np.einsum('bi,bij->bj', q[:, 7 + 126:10 + 126] - q[:, a:a + 3], mat))
+      np.einsum('bi,bij->bj', q[:, 126:129] - q[:, a:a + 3], mat))
   # arena features: 2-vectors use the upper-left block; the away team sees the
   # pitch from the other end (its own goal is the away goal)
   np.testing.assert_allclose(
@@ -176,7 +176,7 @@ def test_observables_are_egocentric(model):
       o['field_front_left'],
       np.einsum('bi,bij->bj', pitch.field[1] - q[:, a:a + 2], mat[:, :2, :2]))
   away = obs[2]
-  b = 7 + 126
+  b = 126
   mat2 = soccer._quat_to_mat(q[:, b + 3:b + 7])
   np.testing.assert_allclose(
       away['team_goal_mid'], np.einsum('bi,bij->bj', pitch.away_goal[2] - q[:, b:b + 3], mat2))
