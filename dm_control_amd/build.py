@@ -84,15 +84,24 @@ COOP_MAX_SGPR_SPILLS = 640
 _FP32_FLAGS = ('-fno-hip-fp32-correctly-rounded-divide-sqrt', '-freciprocal-math')
 
 
+# "rolled" has to mean rolled: the AMDGPU backend raises the unroll thresholds
+# of loops that index private arrays (to promote them to registers), which
+# turned the generic loops of mid-size models back into straight-line code --
+# the rolled fp64 build of the 62-dof walker spilled 14591 VGPRs, took 68 s to
+# compile and returned a wrong mass-matrix factor on the GPU (round 3).  With
+# the loop unroller off the same build spills nothing and compiles in 5 s.
+_ROLLED_FLAGS = ('-fno-unroll-loops',)
+
+
 def model_key(model, task, precision, ncon_max=None, extra_flags=(),
               unroll=True):
   src = os.path.join(_CSRC, 'dmc_kernels.hip')
   h = hashlib.sha1()
   h.update(model.content_hash().encode())
-  h.update(('%d/%s/%r/%r/%s/%d/%s' % (
+  h.update(('%d/%s/%r/%r/%s/%d/%s/%s' % (
       task, precision, ncon_max, tuple(extra_flags),
       os.environ.get('DMC_PRAGMA_UNROLL_THRESHOLD', ''), int(unroll),
-      ' '.join(_FP32_FLAGS))).encode())
+      ' '.join(_FP32_FLAGS), '' if unroll else ' '.join(_ROLLED_FLAGS))).encode())
   for path in (src, os.path.join(_CSRC, 'dmc_coop.hip'),
                os.path.join(_CSRC, 'dmc_args.h'), codegen.__file__):
     with open(path, 'rb') as f:
@@ -191,6 +200,8 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
            '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast']
   flags[0:0] = list(extra_flags)
   flags[0:0] = ['-DDMC_REAL_IS_DOUBLE'] if precision == 'f64' else list(_FP32_FLAGS)
+  if not unroll:
+    flags += list(_ROLLED_FLAGS)
   if backend() == 'hiprtc':
     with open(header) as f:
       code, log = _compile_in_process(f.read(), source, flags)
@@ -246,6 +257,8 @@ def code_object_bytes(model, task=codegen.TASK_NONE, precision='f32',
     flags += ['-DDMC_GROUP=%d' % min(coop_group, 64),
               '-DDMC_COOP_DUO=%d' % (coop_group == 128)]
     source, unroll = 'dmc_coop.hip', True
+  if not unroll:
+    flags += list(_ROLLED_FLAGS)
   header = codegen.generate_header(model, task, ncon_max, unroll=unroll)
   return _compile_in_process(header, source, flags)[0]
 
@@ -361,7 +374,15 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     with open(marker, 'w') as f:
       f.write('spills (vgpr, sgpr): %r\n' % (spills,))
   out = path(False)
-  _compile(model, task, precision, ncon_max, extra_flags, False, out,
-           keep_temps)
+  spills = _compile(model, task, precision, ncon_max, extra_flags, False, out,
+                    keep_temps)
+  # a rolled build keeps its per-lane arrays in private memory by design; what
+  # it must not do is spill registers wholesale on top of that
+  if not _within_spill_budget(spills, COOP_MAX_SGPR_SPILLS) and not _allow_overbudget():
+    os.remove(out + '.tmp')
+    raise RuntimeError(
+        'the rolled build of this model spills %r (VGPR, SGPR) registers (budget '
+        '%d / %d); set $DMC_ALLOW_OVERBUDGET=1 to build it anyway'
+        % (spills, MAX_VGPR_SPILLS, COOP_MAX_SGPR_SPILLS))
   os.replace(out + '.tmp', out)
   return out
