@@ -135,6 +135,7 @@ def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None,
   except Exception:  # pylint: disable=broad-except
     lib = oracle.load()
   om = oracle.OracleModel(model, lib)
+  _progress('cpu baseline: oracle loaded')
   cores = usable_cores()
   nenv = (64 if model.nv < 100 else 2)*cores      # a 2v2 pitch is ~13 ms per physics step
   datas = [oracle.OracleData(om) for _ in range(nenv)]
@@ -163,6 +164,7 @@ def cpu_baseline(domain, task, nsub, budget_s=12.0, gpu_batch=None,
       'sample': '%s-%s: %d envs x %d control steps (%d physics steps each), '
                 'fp64 C restatement of mj_step, OpenMP over envs, %.1f s'
                 % (domain, task, nenv, reps, nsub, dt)}
+  _progress('cpu baseline timed: %.3g env-steps/s' % out['value'])
   if gpu_batch is not None:
     out['qpos_rel_err'] = {
         'definition': 'max|q_gpu - q_cpu| / max(1, max|q_cpu|) per env; CPU = '
@@ -291,6 +293,16 @@ def _free_run_sample(gpu_batch, om, oracle, nsub, cores, nenv=64, steps=1000):
   out['sample'] = ('%d envs from the benchmarked batch, %d free-running control '
                    'steps, same code object, U(-1,1) controls' % (nenv, steps))
   return out
+
+
+def _progress(msg):
+  """$DMC_BENCH_PROGRESS=1: stage markers on stderr (long legs: soccer)."""
+  if os.environ.get('DMC_BENCH_PROGRESS'):
+    sys.stderr.write('[bench %.1fs] %s\n' % (time.time() - _T0, msg))
+    sys.stderr.flush()
+
+
+_T0 = time.time()
 
 
 def parse_args(argv=None):
@@ -476,9 +488,12 @@ def measure(domain, task, precision, seeds, local_rank, steps, warmup, in_group)
       state['ev_ms'] += ms; state['ev_launches'] += n
       state['timing'] = False
 
+  _progress('env built (%s), first reset' % physics.kernel_shape)
   reset_episode()
+  _progress('warm-up')
   run(warmup, False)
   batch.sync()
+  _progress('timed region')
   torch.cuda.synchronize(dev)
   if in_group:
     dist.barrier()
@@ -529,6 +544,7 @@ def main(argv=None):
   info = batch.model.info
   nlocal, nsub, elapsed = fig['nlocal'], fig['nsub'], fig['elapsed']
 
+  _progress('timed region done: %.3f s' % elapsed)
   # reporting path: all-gather of per-env episode returns over RCCL/xGMI
   returns = torch.from_numpy(
       batch.read(wrapper.FIELD_RETURN).astype(np.float32)).to(dev)

@@ -100,8 +100,9 @@ def model_key(model, task, precision, ncon_max=None, extra_flags=(),
   h.update(model.content_hash().encode())
   h.update(('%d/%s/%r/%r/%s/%d/%s/%s' % (
       task, precision, ncon_max, tuple(extra_flags),
-      os.environ.get('DMC_PRAGMA_UNROLL_THRESHOLD', ''), int(unroll),
-      ' '.join(_FP32_FLAGS), '' if unroll else ' '.join(_ROLLED_FLAGS))).encode())
+      os.environ.get('DMC_PRAGMA_UNROLL_THRESHOLD', ''), int(unroll is True),
+      ' '.join(_FP32_FLAGS),
+      '' if unroll is True else ('semi' if unroll == 'semi' else ' '.join(_ROLLED_FLAGS)))).encode())
   for path in (src, os.path.join(_CSRC, 'dmc_coop.hip'),
                os.path.join(_CSRC, 'dmc_args.h'), codegen.__file__):
     with open(path, 'rb') as f:
@@ -175,7 +176,7 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
           source, task, precision, ncon_max, tuple(extra_flags), unroll, model.nv, model.nbody))
   header = os.path.join(_BUILD, 'model_%s.h' % key)
   with open(header, 'w') as f:
-    f.write(codegen.generate_header(model, task, ncon_max, unroll=unroll))
+    f.write(codegen.generate_header(model, task, ncon_max, unroll=unroll is True))
   # -pragma-unroll-threshold: the per-model straight-line code is far beyond
   #   LLVM's default budget; without it the pair loop stays rolled, per-lane
   #   arrays are indexed dynamically and the whole working set lands in scratch.
@@ -200,7 +201,7 @@ def _compile(model, task, precision, ncon_max, extra_flags, unroll, out,
            '-ffp-contract=off' if precision == 'f64' else '-ffp-contract=fast']
   flags[0:0] = list(extra_flags)
   flags[0:0] = ['-DDMC_REAL_IS_DOUBLE'] if precision == 'f64' else list(_FP32_FLAGS)
-  if not unroll:
+  if unroll is False:      # (unroll == 'semi': generic source, the backend may unroll)
     flags += list(_ROLLED_FLAGS)
   if backend() == 'hiprtc':
     with open(header) as f:
@@ -350,10 +351,11 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     if mode == 'unrolled' and os.path.exists(over) and not _allow_overbudget():
       with open(over) as f:
         raise RuntimeError(_OVERBUDGET_MSG % f.read().strip())
-    if mode != 'unrolled' and os.path.exists(path(False)) and (
-        mode == 'rolled' or os.path.exists(marker)):
-      return path(False)
-  if mode != 'rolled':
+  # `auto` decided against the unrolled build earlier (marker): straight to the
+  # generic tiers
+  skip_unrolled = mode == 'rolled' or (mode == 'auto' and not force
+                                       and os.path.exists(marker))
+  if not skip_unrolled:
     out = path(True)
     spills = _compile(model, task, precision, ncon_max, extra_flags, True, out,
                       keep_temps)
@@ -373,11 +375,31 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
     os.remove(out + '.tmp')
     with open(marker, 'w') as f:
       f.write('spills (vgpr, sgpr): %r\n' % (spills,))
+  # Generic ("rolled") source, two tiers.  First with the backend's loop unroller
+  # left on: for small models it turns the per-lane loops back into mostly
+  # straight-line code within the spill budget (cheetah fp64: 14 VGPR / 300 SGPR
+  # spills, 0.33 ms per launch against 1.33 ms strictly rolled).  Beyond the
+  # budget -- mid-size models: humanoid fp64 3644, the 62-dof walker 14591 spilled
+  # VGPRs -- the strictly rolled form (-fno-unroll-loops: no spills at all).
+  semi = path('semi')
+  if not force and not os.path.exists(semi + '.strict'):
+    if os.path.exists(semi) and os.path.exists(semi + '.ok'):
+      return semi
+    spills = _compile(model, task, precision, ncon_max, extra_flags, 'semi', semi,
+                      keep_temps)
+    if _within_spill_budget(spills, COOP_MAX_SGPR_SPILLS):
+      os.replace(semi + '.tmp', semi)
+      with open(semi + '.ok', 'w') as f:
+        f.write('%r' % (spills,))
+      return semi
+    os.remove(semi + '.tmp')
+    with open(semi + '.strict', 'w') as f:
+      f.write('spills (vgpr, sgpr) with the loop unroller on: %r\n' % (spills,))
   out = path(False)
+  if not force and os.path.exists(out):
+    return out
   spills = _compile(model, task, precision, ncon_max, extra_flags, False, out,
                     keep_temps)
-  # a rolled build keeps its per-lane arrays in private memory by design; what
-  # it must not do is spill registers wholesale on top of that
   if not _within_spill_budget(spills, COOP_MAX_SGPR_SPILLS) and not _allow_overbudget():
     os.remove(out + '.tmp')
     raise RuntimeError(
