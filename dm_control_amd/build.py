@@ -74,6 +74,7 @@ MAX_SGPR_SPILLS = 128
 # is the same thing as above: builds that spill VGPRs wholesale to scratch
 # (the 62-dof soccer walker: 1652 fp32 / 6552 fp64).
 COOP_MAX_SGPR_SPILLS = 640
+SEMI_ROLLED_MAX_NV = 16     # see build_model: the generic tier with the backend unroller on
 
 
 # fp32 builds: v_rcp / v_rsq based division and sqrt (<= 2.5 ulp) instead of the
@@ -381,8 +382,13 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
   # spills, 0.33 ms per launch against 1.33 ms strictly rolled).  Beyond the
   # budget -- mid-size models: humanoid fp64 3644, the 62-dof walker 14591 spilled
   # VGPRs -- the strictly rolled form (-fno-unroll-loops: no spills at all).
+  # Only small models take this tier: it is the regime every GPU parity test of
+  # a suite fp64 build covers, and the one time the unroller was let loose on a
+  # big model (the 2v2 pitch) it produced wrong code (csrc/dmc_kernels.hip,
+  # DMC_KEEP_ROLLED).
   semi = path('semi')
-  if not force and not os.path.exists(semi + '.strict'):
+  if (not force and not os.path.exists(semi + '.strict') and model.nv <= SEMI_ROLLED_MAX_NV
+      and os.environ.get('DMC_ROLLED_STRICT') != '1'):   # (experiments: skip this tier)
     if os.path.exists(semi) and os.path.exists(semi + '.ok'):
       return semi
     spills = _compile(model, task, precision, ncon_max, extra_flags, 'semi', semi,

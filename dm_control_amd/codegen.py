@@ -315,6 +315,7 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   w('typedef float dmc_real;')
   w('#endif')
   w('#define DMC_UNROLL %s' % ('_Pragma("unroll")' if unroll else ''))
+  w('#define DMC_GENERIC_BUILD %d' % (0 if unroll else 1))
   # the static pair list is unrolled only while it stays small; larger models
   # keep a rolled narrowphase loop over a per-lane geom-pose mirror
   import os
@@ -486,6 +487,15 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   ti('geom_tree', [tree_of_body[int(b)] for b in m.geom_bodyid] or [-1])
   ti('pair_tree1', [tree_of_body[int(m.geom_bodyid[p[0]])] for p in pairs] or [-1])
   ti('pair_tree2', [tree_of_body[int(m.geom_bodyid[p[1]])] for p in pairs] or [-1])
+  # length of the run of consecutive pairs, from p on, between the same two
+  # (different) trees: a far-apart pair of walkers skips the whole run at once
+  keys = [(tree_of_body[int(m.geom_bodyid[a])], tree_of_body[int(m.geom_bodyid[b])],
+           float(mx['margin'])) for (a, b), mx in zip(pairs, mixed)]
+  run = [1]*len(pairs)
+  for i in range(len(pairs) - 2, -1, -1):
+    if keys[i] == keys[i + 1] and keys[i][0] >= 0 and keys[i][1] >= 0 and keys[i][0] != keys[i][1]:
+      run[i] = run[i + 1] + 1
+  ti('pair_run', run or [1])
   ti('pair_b1', [int(m.geom_bodyid[p[0]]) for p in pairs])
   ti('pair_b2', [int(m.geom_bodyid[p[1]]) for p in pairs])
   ci('MAXCHAIN', maxchain)

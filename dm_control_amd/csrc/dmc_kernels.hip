@@ -96,6 +96,17 @@ constexpr bool MAT_IN_WS = false;
 #else
 constexpr bool MAT_IN_WS = (long long)NM*(long long)sizeof(real) > DMC_MAT_PRIVATE_BYTES;
 #endif
+// The two 18-element clears of a free joint's translational cdof / cdof_dot must
+// stay loops in the generic builds: with the backend allowed to unroll them FULLY
+// (trip count 18; `-unroll-full-max-count=16` is enough to avoid it) the 2v2
+// pitch build returned a wrong mass matrix on gfx950 -- no spills involved, host
+// build clean under ASan/UBSan (profiles/r03_unroll_18_*).
+// -DDMC_UNROLL_18=1 restores the faulty form (tools/debug/pitch_tiers.py).
+#if DMC_GENERIC_BUILD && !defined(DMC_UNROLL_18) && !defined(DMC_HOST_SHIM)
+#define DMC_KEEP_ROLLED _Pragma("nounroll")
+#else
+#define DMC_KEEP_ROLLED
+#endif
 constexpr int MAT_REGS = MAT_IN_WS ? 1 : (NM > 0 ? NM : 1);
 constexpr int NVX = NV > 0 ? NV : 1;
 constexpr int NUX = NU > 0 ? NU : 1;
@@ -326,33 +337,80 @@ struct LoArr {
   const int* p;
   __device__ __forceinline__ int operator()(int i) const { return p[i]; }
 };
+// The matrices of a big scene live in HBM: a lone wave hides that latency only
+// if several loads are in flight, and the generic builds compile with the loop
+// unroller off -- so the inner loops are blocked by eight by hand: eight loads
+// first, then the arithmetic IN THE ORIGINAL ORDER (same rounding as the plain
+// loop).
+template <class Mat>
+DEV real env_dot_sub(real t, const Mat& A, int base, const real* v, int k0, int k1) {
+  int k = k0;
+  for (; k + 32 <= k1; k += 32) {        // 32 HBM loads in flight
+    real a[32];
+    _Pragma("unroll") for (int u = 0; u < 32; u++) a[u] = A.get(base + k + u);
+    _Pragma("unroll") for (int u = 0; u < 32; u++) t -= a[u]*v[k + u];
+  }
+  for (; k + 8 <= k1; k += 8) {
+    real a[8];
+    _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = A.get(base + k + u);
+    _Pragma("unroll") for (int u = 0; u < 8; u++) t -= a[u]*v[k + u];
+  }
+  for (; k < k1; k++) t -= A.get(base + k)*v[k];
+  return t;
+}
 template <class Mat, class Lo>
 DEV void symv_env(real* y, const Mat& A, const real* x, const Lo& lo) {
   for (int i = 0; i < NV; i++) y[i] = 0;
-  for (int i = 0; i < NV; i++)
-    for (int j = lo(i); j <= i; j++) {
-      const real a = A.get(tri(i, j));
-      y[i] += a*x[j];
-      if (j != i) y[j] += a*x[i];
+  for (int i = 0; i < NV; i++) {
+    const int base = tri(i, 0);
+    const real xi = x[i];
+    real yi = y[i];
+    int j = lo(i);
+    for (; j + 8 <= i; j += 8) {           // strictly below the diagonal
+      real a[8];
+      _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = A.get(base + j + u);
+      _Pragma("unroll") for (int u = 0; u < 8; u++) { yi += a[u]*x[j + u]; y[j + u] += a[u]*xi; }
     }
+    for (; j < i; j++) {
+      const real a = A.get(base + j);
+      yi += a*x[j];
+      y[j] += a*xi;
+    }
+    y[i] = yi + A.get(base + i)*xi;
+  }
 }
-template <class Mat, class Lo>
-DEV int chol_factor_env(const Mat& A, const Lo& lo) {
+// hi[j]: last row whose envelope reaches column j (>= j), from lo[]: the rows of
+// the factorisation's column sweep -- scanning all NV rows per column with a
+// table look-up each was most of its time
+DEV void env_last_rows(int* hi, const int* lo) {
+  for (int j = 0; j < NV; j++) hi[j] = j;
+  for (int i = 0; i < NV; i++) { const int l = lo[i]; if (hi[l] < i) hi[l] = i; }
+  for (int j = 1; j < NV; j++) if (hi[j] < hi[j - 1]) hi[j] = hi[j - 1];
+}
+template <class Mat>
+DEV int chol_factor_env(const Mat& A, const int* lo, const int* hi) {
   int nbad = 0;
   for (int j = 0; j < NV; j++) {
     real rowj[NVX];
-    const int lj = lo(j);
-    real s = A.get(tri(j, j));
-    for (int k = lj; k < j; k++) { rowj[k] = A.get(tri(j, k)); s -= rowj[k]*rowj[k]; }
+    const int lj = lo[j], bj = tri(j, 0);
+    real s = A.get(bj + j);
+    int k = lj;
+    for (; k + 8 <= j; k += 8) {
+      real a[8];
+      _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = A.get(bj + k + u);
+      _Pragma("unroll") for (int u = 0; u < 8; u++) { rowj[k + u] = a[u]; s -= a[u]*a[u]; }
+    }
+    for (; k < j; k++) { rowj[k] = A.get(bj + k); s -= rowj[k]*rowj[k]; }
     if (!(s >= DMC_MINVAL)) { s = DMC_MINVAL; nbad++; }
     const real inv = rsqrt_(s);
-    A.set(tri(j, j), inv);
-    for (int i = j + 1; i < NV; i++) {
-      const int li = lo(i);
+    A.set(bj + j, inv);
+    const int last = hi[j];
+    for (int i = j + 1; i <= last; i++) {
+      const int li = lo[i];
       if (li > j) continue;
-      real t = A.get(tri(i, j));
-      for (int k = li > lj ? li : lj; k < j; k++) t -= A.get(tri(i, k))*rowj[k];
-      A.set(tri(i, j), t*inv);
+      const int bi = tri(i, 0);
+      const real t = env_dot_sub(A.get(bi + j), A, bi, rowj, li > lj ? li : lj, j);
+      A.set(bi + j, t*inv);
     }
   }
   return nbad;
@@ -360,22 +418,35 @@ DEV int chol_factor_env(const Mat& A, const Lo& lo) {
 template <class Mat, class Lo>
 DEV void chol_solve_env(real* x, const Mat& L, const Lo& lo) {
   for (int i = 0; i < NV; i++) {
-    real s = x[i];
-    for (int k = lo(i); k < i; k++) s -= L.get(tri(i, k))*x[k];
-    x[i] = s*L.get(tri(i, i));
+    const int bi = tri(i, 0);
+    x[i] = env_dot_sub(x[i], L, bi, x, lo(i), i)*L.get(bi + i);
   }
   for (int i = NV - 1; i >= 0; i--) {     // row i of L pushes x[i] into the earlier entries
-    const real xi = x[i]*L.get(tri(i, i));
+    const int bi = tri(i, 0);
+    const real xi = x[i]*L.get(bi + i);
     x[i] = xi;
-    for (int k = lo(i); k < i; k++) x[k] -= L.get(tri(i, k))*xi;
+    int k = lo(i);
+    for (; k + 8 <= i; k += 8) {
+      real a[8];
+      _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = L.get(bi + k + u);
+      _Pragma("unroll") for (int u = 0; u < 8; u++) x[k + u] -= a[u]*xi;
+    }
+    for (; k < i; k++) x[k] -= L.get(bi + k)*xi;
   }
 }
 // dst = src inside dst's envelope `lo`; src is zero left of `slo`
 template <class Mat, class Lo, class SLo>
 DEV void copy_env(const Mat& dst, const Mat& src, const Lo& lo, const SLo& slo) {
   for (int i = 0; i < NV; i++) {
-    const int si = slo(i);
-    for (int j = lo(i); j <= i; j++) dst.set(tri(i, j), j >= si ? src.get(tri(i, j)) : R(0));
+    const int si = slo(i), bi = tri(i, 0);
+    int j = lo(i);
+    for (; j < si && j <= i; j++) dst.set(bi + j, R(0));
+    for (; j + 8 <= i + 1; j += 8) {
+      real a[8];
+      _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = src.get(bi + j + u);
+      _Pragma("unroll") for (int u = 0; u < 8; u++) dst.set(bi + j + u, a[u]);
+    }
+    for (; j <= i; j++) dst.set(bi + j, src.get(bi + j));
   }
 }
 
@@ -400,12 +471,15 @@ struct Env {
   real subtree_linvel[NBODY*3];
   real touch[NTOUCH > 0 ? NTOUCH : 1];   // touch sensor readings (mj_sensorAcc)
   real taskdata[NTDX];                   // per-instance task parameters
-#ifdef DMC_SOLVER_PROFILE
+#if defined(DMC_SOLVER_PROFILE) || defined(DMC_STEP_PROFILE)
   real prof[8];
 #endif
   int ncon, nefc, nefc_limit, iters;
   int nmerged;     // pyramid edge pairs stored as one row (PLANAR_MERGE)
-  int hlo[MAT_IN_WS ? NVX : 1];   // big scenes: envelope of the Newton Hessian (first column per row)
+  // big scenes: envelope of the Newton Hessian (first column per row, last row per
+  // column) and of M (the kinematic trees; filled once per launch)
+  int hlo[MAT_IN_WS ? NVX : 1], hhi[MAT_IN_WS ? NVX : 1];
+  int mlo[MAT_IN_WS ? NVX : 1], mhi[MAT_IN_WS ? NVX : 1];
   unsigned warn;
 };
 
@@ -694,7 +768,7 @@ DEV void com_pos(Env& E) {
     real* cd = E.cdof + 6*da;
     if (jnt_type[j] == JNT_FREE || jnt_type[j] == JNT_BALL) {
       if (jnt_type[j] == JNT_FREE) {
-        DMC_UNROLL
+        DMC_UNROLL DMC_KEEP_ROLLED
         for (int k = 0; k < 18; k++) cd[k] = 0;
         cd[3] = 1; cd[6 + 4] = 1; cd[12 + 5] = 1;
         cd += 18;
@@ -751,7 +825,7 @@ DEV void crb_factor(Env& E, const Work& W) {
   }
   if (MAT_IN_WS) {
     copy_env(L, M, LoTree{}, LoTree{});
-    if (chol_factor_env(L, LoTree{})) E.warn |= WARN_INERTIA;
+    if (chol_factor_env(L, E.mlo, E.mhi)) E.warn |= WARN_INERTIA;
     return;
   }
   DMC_UNROLL
@@ -777,7 +851,7 @@ DEV void com_vel(Env& E) {
       int da = jnt_dofadr[jid];
       if (jnt_type[jid] == JNT_FREE || jnt_type[jid] == JNT_BALL) {
         if (jnt_type[jid] == JNT_FREE) {
-          DMC_UNROLL
+          DMC_UNROLL DMC_KEEP_ROLLED
           for (int k = 0; k < 18; k++) E.cdof_dot[6*da + k] = 0;
           DMC_UNROLL
           for (int k = 0; k < 3; k++)
@@ -994,6 +1068,23 @@ DEV bool push_row(Env& E, const Work& W, const real* row, real pos_minus_margin,
   return true;
 }
 
+// a row with the single entry `value` at `dof` (joint limits of big scenes)
+template <class Row>
+DEV void write_row_1(const Row& rec, const Env& E, int dof, real value, real pm,
+                     real K, real B, real imp, real Rrow) {
+  rec.set(dof, value);
+  rec.set(ROW_LO, (real)dof); rec.set(ROW_HI, (real)dof);
+  rec.set(ROW_AREF, -B*(value*E.qvel[dof]) - K*imp*pm);
+  rec.set(ROW_D, R(1)/(Rrow < DMC_MINVAL ? DMC_MINVAL : Rrow));
+}
+DEV bool push_row_1(Env& E, const Work& W, int dof, real value, real pm,
+                    real K, real B, real imp, real Rrow) {
+  if (E.nefc >= NEFC_MAX) { E.warn |= WARN_CNSTRFULL; return false; }
+  const int r = E.nefc++;
+  if (LDS_ROWS >= NEFC_MAX || r < LDS_ROWS) write_row_1(W.lrow(r), E, dof, value, pm, K, B, imp, Rrow);
+  else write_row_1(W.grow(r), E, dof, value, pm, K, B, imp, Rrow);
+  return true;
+}
 DEV void limit_rows(Env& E, const Work& W) {
   if (DISABLEFLAGS & (DSBL_LIMIT | DSBL_CONSTRAINT)) return;
   DMC_UNROLL
@@ -1005,14 +1096,18 @@ DEV void limit_rows(Env& E, const Work& W) {
     for (int side = -1; side <= 1; side += 2) {
       const real dist = side < 0 ? q - R(jnt_range[2*j]) : R(jnt_range[2*j + 1]) - q;
       if (dist < margin) {
-        real row[NVX];
-        DMC_UNROLL
-        for (int k = 0; k < NV; k++) row[k] = 0;
-        row[dof] = -(real)side;
         const real pm = dist - margin;
         const real imp = impedance(limit_solimp + 5*l, pm);
         const real Rr = (1 - imp)*R(dof_invweight0[dof])/imp;
-        push_row(E, W, row, pm, R(limit_K[l]), R(limit_B[l]), imp, Rr);
+        if (MAT_IN_WS) {      // the record of a one-dof row, written directly
+          push_row_1(E, W, dof, -(real)side, pm, R(limit_K[l]), R(limit_B[l]), imp, Rr);
+        } else {
+          real row[NVX];
+          DMC_UNROLL
+          for (int k = 0; k < NV; k++) row[k] = 0;
+          row[dof] = -(real)side;
+          push_row(E, W, row, pm, R(limit_K[l]), R(limit_B[l]), imp, Rr);
+        }
       }
     }
   }
@@ -1442,17 +1537,28 @@ DEV int collide_pair(const Poses& G, int p, RawCon* rc) {
   const int g1 = pair_g1[p], g2 = pair_g2[p];
   const int t1 = geom_type[g1], t2 = geom_type[g2];
   const real margin = R(pair_margin[p]);
+  // positions (and a plane's normal) first: most pairs end at the bounding-sphere
+  // test, and where the pose mirror lives in HBM (big scenes) the 18 words of the
+  // two rotation matrices are not worth fetching for those
   real p1[3], m1[9], p2[3], m2[9];
-  geom_pose(G, g1, p1, m1);
-  geom_pose(G, g2, p2, m2);
-  const real s1[3] = {R(geom_size[3*g1]), R(geom_size[3*g1 + 1]), R(geom_size[3*g1 + 2])};
-  const real s2[3] = {R(geom_size[3*g2]), R(geom_size[3*g2 + 1]), R(geom_size[3*g2 + 2])};
+  DMC_UNROLL
+  for (int k = 0; k < 3; k++) { p1[k] = G.get(12*g1 + k); p2[k] = G.get(12*g2 + k); }
   real dif[3];
   DMC_UNROLL
   for (int k = 0; k < 3; k++) dif[k] = p2[k] - p1[k];
   if (t1 == GEOM_PLANE) {
+    const real nn[3] = {G.get(12*g1 + 3 + 2), G.get(12*g1 + 3 + 5), G.get(12*g1 + 3 + 8)};
+    if (dot3(dif, nn) > R(geom_rbound[g2]) + margin) return 0;
+  } else {
+    const real bound = R(geom_rbound[g1]) + R(geom_rbound[g2]) + margin;
+    if (dot3(dif, dif) > bound*bound) return 0;
+  }
+  DMC_UNROLL
+  for (int k = 0; k < 9; k++) { m1[k] = G.get(12*g1 + 3 + k); m2[k] = G.get(12*g2 + 3 + k); }
+  const real s1[3] = {R(geom_size[3*g1]), R(geom_size[3*g1 + 1]), R(geom_size[3*g1 + 2])};
+  const real s2[3] = {R(geom_size[3*g2]), R(geom_size[3*g2 + 1]), R(geom_size[3*g2 + 2])};
+  if (t1 == GEOM_PLANE) {
     const real n[3] = {m1[2], m1[5], m1[8]};
-    if (dot3(dif, n) > R(geom_rbound[g2]) + margin) return 0;
     if (t2 == GEOM_SPHERE) return plane_sphere(rc, margin, p1, n, p2, s2[0]);
     if (t2 == GEOM_CAPSULE) {
       const real ax[3] = {m2[2], m2[5], m2[8]};
@@ -1491,10 +1597,6 @@ DEV int collide_pair(const Poses& G, int p, RawCon* rc) {
       return (1 << cnt) - 1;
     }
     return 0;
-  }
-  {
-    const real bound = R(geom_rbound[g1]) + R(geom_rbound[g2]) + margin;
-    if (dot3(dif, dif) > bound*bound) return 0;
   }
   if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE)
     return sphere_sphere(rc, margin, p1, p2, s1[0], s2[0]);
@@ -1604,7 +1706,13 @@ DEV void detect_contacts(Env& E, const Work& W) {
           d2 += d*d;
         }
         const real reach = trad[t1] + trad[t2] + R(pair_margin[p]);
-        if (d2 > reach*reach) continue;
+        // (margins are per pair; the run is skipped only if its first pair is
+        // out of reach by more than any margin could bridge: margin 0 here, a
+        // positive one re-tests pair by pair)
+        if (d2 > reach*reach) {
+          if (pair_margin[p] == 0) p += pair_run[p] - 1;
+          continue;
+        }
       }
     }
     RawCon rc[4];
@@ -1816,6 +1924,7 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
       for (int j = lo; j <= hi; j++)
         if (rec.get(j) != 0 && lo < E.hlo[j]) E.hlo[j] = lo;
     });
+    env_last_rows(E.hhi, E.hlo);
     symv_env(Ma, M, E.qacc, LoTree{});
     copy_env(H, M, LoArr{E.hlo}, LoTree{});
   } else {
@@ -1888,7 +1997,7 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
     for (int i = 0; i < NV; i++) search[i] = -grad[i];
     if (MAT_IN_WS) {
       copy_env(F, H, LoArr{E.hlo}, LoArr{E.hlo});
-      chol_factor_env(F, LoArr{E.hlo});
+      chol_factor_env(F, E.hlo, E.hhi);
       chol_solve_env(search, F, LoArr{E.hlo});
     } else {
       DMC_UNROLL
@@ -2077,18 +2186,34 @@ DEV void touch_sensors(Env& E, const Work& W) {
 }
 
 // forward dynamics at (qpos, qvel, ctrl): fills qacc and the force terms
+// -DDMC_STEP_PROFILE (experiments, tools/debug/pitch_profile.py): 100 MHz stamps
+// per stage of forward(), summed per lane into E.prof[0..6], written over the
+// first words of the aux xpos output
+#ifdef DMC_STEP_PROFILE
+#define FPROF(k) do { const long long t_ = wall_clock64(); E.prof[k] += (real)(t_ - tf_); tf_ = t_; } while (0)
+#else
+#define FPROF(k) do {} while (0)
+#endif
 DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
+#ifdef DMC_STEP_PROFILE
+  long long tf_ = wall_clock64();
+#endif
   kinematics(E);
   com_pos(E);
+  FPROF(0);
   crb_factor(E, W);
+  FPROF(1);
   com_vel(E);
   smooth_forces(E, W, actuation);
+  FPROF(2);
   E.ncon = 0; E.nefc = 0; E.iters = 0; E.nmerged = 0;
   limit_rows(E, W);
   E.nefc_limit = E.nefc;
+  FPROF(3);
 #ifndef DMC_ABLATE_CONTACT
   if (NPAIR > 0) contact_rows(E, W);
 #endif
+  FPROF(4);
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qfrc_constraint[i] = 0;
 #ifdef DMC_ABLATE_SOLVER
@@ -2129,6 +2254,7 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     for (int i = 0; i < NV; i++) E.qacc[i] = use_warm ? E.warm[i] : E.qacc_smooth[i];
     solve_newton(E, W, tol, !use_warm);
   }
+  FPROF(5);
   if (NTOUCH > 0) touch_sensors(E, W);
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.warm[i] = E.qacc[i];
@@ -2257,7 +2383,7 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
         qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
       }
       if (MAT_IN_WS) {
-        chol_factor_env(A, LoTree{});
+        chol_factor_env(A, E.mlo, E.mhi);
         chol_solve_env(qacc, A, LoTree{});
       } else {
         chol_factor(A);
@@ -2615,9 +2741,13 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
 #endif
   DMC_UNROLL
   for (int i = 0; i < NTASKDATA; i++) E.taskdata[i] = a.taskdata[sidx(i, e, n, NTDX)];
-#ifdef DMC_SOLVER_PROFILE
+#if defined(DMC_SOLVER_PROFILE) || defined(DMC_STEP_PROFILE)
   for (int k = 0; k < 8; k++) E.prof[k] = 0;
 #endif
+  if (MAT_IN_WS) {
+    for (int i = 0; i < NV; i++) E.mlo[i] = dof_treeroot[i];
+    env_last_rows(E.mhi, E.mlo);
+  }
   E.warn = 0; E.ncon = 0; E.nefc = 0; E.nefc_limit = 0; E.iters = 0; E.nmerged = 0;
   DMC_UNROLL
   for (int s = 0; s < (NTOUCH > 0 ? NTOUCH : 1); s++) E.touch[s] = 0;
@@ -2751,6 +2881,9 @@ dmc_step(DmcArgs a) {
 #ifdef DMC_SOLVER_PROFILE
   __syncthreads();
   for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
+#endif
+#ifdef DMC_STEP_PROFILE
+  if (a.xpos) for (int k = 0; k < 8; k++) a.xpos[(long long)k*n + e] = E.prof[k];
 #endif
   store_env(E, a, e, time);
 }
