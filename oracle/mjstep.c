@@ -1273,7 +1273,8 @@ static void mjo_reference_constraint(const mjoModel* m, mjoData* d) {
       int rows = 2*(c->dim - 1), j;
       double rpy = 2*c->friction[0]*c->friction[0]*d->efc_R[i];
       rpy = fmax(MINVAL, rpy);
-      for (j = 0; j < rows; j++) d->efc_R[i + j] = rpy;
+      /* (a contact cut short by the row capacity has fewer rows than `rows`) */
+      for (j = 0; j < rows && i + j < d->nefc; j++) d->efc_R[i + j] = rpy;
       i += rows - 1;
     }
   for (i = 0; i < d->nefc; i++) d->efc_D[i] = 1/d->efc_R[i];

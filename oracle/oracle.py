@@ -104,6 +104,11 @@ class OracleModel:
             a.size)
       if rc != 0:
         raise RuntimeError('oracle rejected model field %r' % name)
+    # capacities: the C defaults (128 contacts, 600 rows) suit one walker; scenes
+    # with several get room in proportion (the reference: 200 per player, task.py:105-108)
+    if model.nv > 64:
+      self.set_int('nconmax', 128 + model.nv)
+      self.set_int('nefcmax', 600 + 4*model.nv)
 
   def set_int(self, name, value):
     if self.lib.mjo_model_set_int(self.ptr, name.encode(), int(value)) != 0:

@@ -414,3 +414,21 @@ def test_soccer_environment_plays():
   z = np.asarray(env.physics.data.qpos)[:, [63*k + 2 for k in range(4)]]
   assert (z > 0.05).all() and (z < 1.6).all()
   env.physics.free()
+
+
+def test_oracle_at_its_row_capacity_flags_and_stays_in_bounds():
+  """mjWARN_CNSTRFULL instead of a write past the row arrays when a pyramidal
+  contact is cut short by the capacity (the bench's CPU leg ran into exactly
+  that with four fallen humanoids and the C default of 600 rows)."""
+  m = compiler.from_xml_string(soccer.build(2, with_ball=False))
+  om = oracle.OracleModel(m)
+  om.set_int('nefcmax', 70)
+  d = oracle.OracleData(om)
+  d.qpos[2] = d.qpos[65] = 0.08           # both walkers flat on the ground: many contacts
+  d.qpos[3:7] = d.qpos[66:70] = [1, 0, 0, 0]
+  d.step1()
+  top = 0
+  for _ in range(12):
+    d.physics_step()
+    top = max(top, d.nefc)
+  assert top == 70 and d.warning[2] > 0 and np.isfinite(d.qpos).all()
