@@ -288,18 +288,28 @@ def build_model(model, task=codegen.TASK_NONE, precision='f32',
 
   mode: "unrolled" (static indexing, per-lane state in registers), "rolled"
   (generic loops, per-lane arrays in scratch) or "auto" (unrolled unless its
-  register spills exceed MAX_*_SPILLS), or "coop": `group` lanes advance one
+  register spills exceed MAX_*_SPILLS), "team" (the rolled source with the 64
+  lanes of a wavefront sharing ONE env: scenes whose matrices live in the HBM
+  workspace, e.g. a soccer pitch), or "coop": `group` lanes advance one
   env together with its working set in LDS (csrc/dmc_coop.hip; the shape for
   nv ~ 20+ models and for small shards; 128 = 64 lanes + a helper wavefront).  Returns the path of the gfx950 code
   object; cached in-tree by content hash.
   """
   if precision not in ('f32', 'f64', 'mixed'):
     raise ValueError('precision must be "f32", "f64" or "mixed"')
-  if mode not in ('auto', 'unrolled', 'rolled', 'coop'):
-    raise ValueError('mode must be auto, unrolled, rolled or coop')
+  if mode not in ('auto', 'unrolled', 'rolled', 'coop', 'team'):
+    raise ValueError('mode must be auto, unrolled, rolled, coop or team')
   if extra_flags is None:
     # experiment hook: extra -D flags for ablation builds (never set in tests)
     extra_flags = tuple(os.environ.get('DMC_EXTRA_FLAGS', '').split())
+  if mode == 'team':
+    # big scenes: the generic source with one wavefront per env (csrc/dmc_kernels.hip,
+    # "team mode"): matrices, rows and contacts in the HBM workspace, a tree's
+    # diagonal block at a time in LDS
+    if precision == 'mixed':
+      raise ValueError('precision "mixed" is built for the one-env-per-lane kernel')
+    extra_flags = tuple(extra_flags) + ('-DDMC_TEAM=64',)
+    mode = 'rolled'
   if precision == 'mixed':
     # fp32 arithmetic, qpos/qvel carried between steps as fp64 (high, low)
     # pairs (csrc/dmc_kernels.hip, DMC_STATE_COMP); one-env-per-lane kernel only

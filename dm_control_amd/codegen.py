@@ -472,6 +472,16 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
       d = int(m.dof_parentid[d])
     treeroot.append(d)
   ti('dof_treeroot', treeroot or [0])
+  # the same as dof ranges [lo, hi] per tree (a tree's dofs are consecutive): the
+  # diagonal blocks that the team build of a big scene factors one LDS tile at a time
+  starts = sorted(set(treeroot))
+  ends = [max(i for i, t in enumerate(treeroot) if t == s0) for s0 in starts]
+  for s0, e0 in zip(starts, ends):
+    assert all(treeroot[i] == s0 for i in range(s0, e0 + 1)), 'tree dofs not consecutive'
+  ci('NDTREE', len(starts))
+  ti('dtree_lo', starts or [0])
+  ti('dtree_hi', ends or [0])
+  ci('MAXTREEDOF', max([e0 - s0 + 1 for s0, e0 in zip(starts, ends)] or [0]))
   # [body][word]: bit (j & 31) of word (j >> 5) set <=> dof j moves the body
   # (multi-word, so scenes with several walkers -- nv > 64 -- compile too)
   nmaskw = max(1, (m.nv + 31)//32)

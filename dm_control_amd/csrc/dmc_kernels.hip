@@ -80,6 +80,115 @@ using namespace dmc_model;
 #define DEV static __device__ __forceinline__
 #define DEVN static __device__ __forceinline__
 
+// ---------------------------------------------------------------------------
+// Team mode (-DDMC_TEAM=64, big scenes only): the TEAM lanes of a wavefront
+// advance ONE env together.  Every lane runs the whole step and keeps its own
+// copy of the per-env vectors (positions, velocities, forces: identical in all
+// lanes, so control flow stays uniform); the work on what is shared -- the
+// matrices, constraint rows and contact records in the HBM workspace -- is
+// split over the lanes: each shared word has one writer per phase, phases end
+// with tsync().  Sums over lanes are butterflies, so every lane ends with the
+// bitwise-identical total.  (One env per lane leaves a 1024-pitch batch with 16
+// wavefronts on a 1024-SIMD chip; a wavefront per pitch fills it.)
+// ---------------------------------------------------------------------------
+#ifdef DMC_TEAM
+constexpr int TEAM = DMC_TEAM;
+static_assert(TEAM >= 2 && TEAM <= 64 && (TEAM & (TEAM - 1)) == 0, "team = power of two <= 64");
+#ifdef DMC_COOP_BUILD
+#error "team mode belongs to dmc_kernels.hip"
+#endif
+#else
+constexpr int TEAM = 1;
+#endif
+constexpr bool TEAMED = TEAM > 1;
+
+#if defined(DMC_TEAM) && !defined(DMC_HOST_SHIM)
+DEV int tlane() { return (int)(threadIdx.x & (TEAM - 1)); }
+// phase boundary: the lanes of a wavefront run in lock step and the memory
+// pipeline keeps one wavefront's accesses in order, so what has to be stopped
+// is the compiler moving accesses across the boundary
+DEV void tsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <class T> DEV T txor(T x, int m) { return __shfl_xor(x, m, TEAM); }
+template <class T> DEV T tup(T x, int d) { return __shfl_up(x, d, TEAM); }
+DEV int tget_bits(int x, int src) {      // `src` uniform
+  if (TEAM == 64) return __builtin_amdgcn_readlane(x, src);
+  return __shfl(x, src, TEAM);
+}
+DEV int tget(int x, int src) { return tget_bits(x, src); }
+DEV unsigned tget(unsigned x, int src) { return (unsigned)tget_bits((int)x, src); }
+DEV float tget(float x, int src) { return __int_as_float(tget_bits(__float_as_int(x), src)); }
+DEV double tget(double x, int src) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)tget_bits((int)(unsigned)(b & 0xffffffffLL), src);
+  const unsigned hi = (unsigned)tget_bits((int)(unsigned)((unsigned long long)b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int CTRL>
+DEV int tdpp_i(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+template <int CTRL> DEV int tdpp(int x) { return tdpp_i<CTRL>(x); }
+template <int CTRL> DEV float tdpp(float x) { return __int_as_float(tdpp_i<CTRL>(__float_as_int(x))); }
+template <int CTRL> DEV double tdpp(double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)tdpp_i<CTRL>((int)(unsigned)(b & 0xffffffffLL));
+  const unsigned hi = (unsigned)tdpp_i<CTRL>((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <class T>
+DEV T tsum(T x) {
+  if (TEAM == 64) {     // inside a 16-lane row: DPP moves; the four row totals: readlane
+    x += tdpp<0xB1>(x);      // xor 1
+    x += tdpp<0x4E>(x);      // xor 2
+    x += tdpp<0x141>(x);     // half-row mirror
+    x += tdpp<0x140>(x);     // row mirror
+    const T r0 = tget(x, 0), r1 = tget(x, 16), r2 = tget(x, 32), r3 = tget(x, 48);
+    return (r0 + r1) + (r2 + r3);
+  }
+  for (int m = TEAM/2; m > 0; m >>= 1) x += txor(x, m);
+  return x;
+}
+#elif defined(DMC_TEAM)      // host shim: one OS thread per lane (tests/host_shim/shim_coop.h)
+DEV int tlane() { return shim_lane(); }
+DEV void tsync() { gsync(); }
+template <class T> DEV T txor(T x, int m) { return gxor(x, m); }
+template <class T> DEV T tup(T x, int d) { return gup(x, d); }
+template <class T> DEV T tget(T x, int src) { return gget(x, src); }
+template <class T>
+DEV T tsum(T x) {
+  for (int m = TEAM/2; m > 0; m >>= 1) x += txor(x, m);
+  return x;
+}
+#else
+DEV int tlane() { return 0; }
+DEV void tsync() {}
+template <class T> DEV T txor(T x, int) { return x; }
+template <class T> DEV T tup(T x, int) { return x; }
+template <class T> DEV T tget(T x, int) { return x; }
+template <class T> DEV T tsum(T x) { return x; }
+#endif
+DEV int tmin(int x) {
+  for (int m = TEAM/2; m > 0; m >>= 1) { const int y = txor(x, m); x = y < x ? y : x; }
+  return x;
+}
+DEV unsigned tor(unsigned x) {
+  for (int m = TEAM/2; m > 0; m >>= 1) x |= txor(x, m);
+  return x;
+}
+DEV bool tany(bool b) { return tor(b ? 1u : 0u) != 0; }
+// exclusive prefix sum in lane order + team total
+DEV int tscan(int x, int& total) {
+  int v = x;
+  for (int d = 1; d < TEAM; d <<= 1) {
+    const int t = tup(v, d);
+    if (tlane() >= d) v += t;
+  }
+  total = tget(v, TEAM - 1);
+  return v - x;
+}
+
 constexpr int NM = NV*(NV + 1)/2;      // packed lower triangle
 constexpr int LANES = 64;               // envs per workgroup = one wavefront
 // Packed nv x nv matrices (M, its factor, the Newton Hessian, Euler's M + h D)
@@ -491,7 +600,8 @@ struct Env {
 // (big scenes, MAT_IN_WS: + the span [lo, hi] of the row's non-zero dofs; the
 // passes over a row then touch only that span -- a joint-limit row is one dof, a
 // foot-ground contact the 62 dofs of one walker, not the 254 of the pitch)
-constexpr int RW = NV + 4 + (MAT_IN_WS ? 2 : 0);
+// (team mode: + the row's pending change of the Hessian, ROW_FLIP = +-D or 0)
+constexpr int RW = NV + 4 + (MAT_IN_WS ? 2 : 0) + (TEAMED ? 1 : 0);
 constexpr int CW = 11;
 #ifndef DMC_LDS_BUDGET
 #define DMC_LDS_BUDGET (128*1024)
@@ -500,7 +610,9 @@ constexpr int CW = 11;
 #define DMC_CON_LDS 12
 #endif
 constexpr int REC_BYTES = LANES*(int)sizeof(real);    // one record word, all lanes
-constexpr int REC_BUDGET = DMC_LDS_BUDGET;
+// (team mode: every row and contact record lives in the workspace, [record][word]
+// contiguous per env; the team's LDS holds the matrix tile being worked on)
+constexpr int REC_BUDGET = TEAMED ? 0 : DMC_LDS_BUDGET;
 constexpr int LDS_CONS_WANT = DMC_CON_LDS < NCON_MAX ? DMC_CON_LDS : NCON_MAX;
 constexpr int LDS_CONS_FIT = (REC_BUDGET/2)/(CW*REC_BYTES);   // <= half the budget
 constexpr int LDS_CONS = LDS_CONS_WANT < LDS_CONS_FIT ? LDS_CONS_WANT : LDS_CONS_FIT;
@@ -510,7 +622,7 @@ static_assert(LDS_CONS >= 0 && LDS_ROWS >= 0, "LDS budget arithmetic");
 constexpr int GLB_ROWS = NEFC_MAX - LDS_ROWS > 0 ? NEFC_MAX - LDS_ROWS : 0;
 constexpr int GLB_CONS = NCON_MAX - LDS_CONS > 0 ? NCON_MAX - LDS_CONS : 0;
 enum { ROW_D = NV, ROW_AREF = NV + 1, ROW_JAR = NV + 2, ROW_JV = NV + 3,
-       ROW_LO = NV + 4, ROW_HI = NV + 5 };
+       ROW_LO = NV + 4, ROW_HI = NV + 5, ROW_FLIP = NV + 6 };
 // span of a row record: compile-time [0, NV) unless the record carries one
 template <class Rec> DEV int row_lo(const Rec& rec) { return MAT_IN_WS ? (int)rec.get(ROW_LO) : 0; }
 template <class Rec> DEV int row_hi(const Rec& rec) { return MAT_IN_WS ? (int)rec.get(ROW_HI) : NV - 1; }
@@ -524,6 +636,16 @@ struct GlbRow {
   real* p; long long n;
   __device__ __forceinline__ real get(int k) const { return p[k*n]; }
   __device__ __forceinline__ void set(int k, real v) const { p[k*n] = v; }
+};
+// team mode: the Jacobian part of a row is contiguous ([row][dof]: a team reads a
+// row with unit-stride loads), the scalar words are kept [word][row], so the
+// passes that run one row per lane (line search) read them with unit stride too
+struct TeamRow {
+  real* j; real* sc;
+  __device__ __forceinline__ real get(int k) const { return k < NV ? j[k] : sc[(k - NV)*NEFC_MAX]; }
+  __device__ __forceinline__ void set(int k, real v) const {
+    if (k < NV) j[k] = v; else sc[(k - NV)*NEFC_MAX] = v;
+  }
 };
 // workspace words per env: overflow rows, overflow contacts, then
 // (-DDMC_STATE_COMP) the low words of the fp64 state: qpos/qvel are then
@@ -551,14 +673,29 @@ template <bool B, class T, class F> struct pick_ { typedef T type; };
 template <class T, class F> struct pick_<false, T, F> { typedef F type; };
 typedef pick_<MAT_IN_WS, GlbMat, RegMat>::type LaneMat;   // where a lane's matrices live
 enum { MAT_M = 0, MAT_L = 1, MAT_H = 2, MAT_A = 3 };
+// team LDS: two vectors for hand-overs between lanes, one row segment, one
+// matrix tile (a kinematic tree's diagonal block, row stride odd)
+constexpr int TB = 64;                  // largest tree (dofs) a team build takes
+constexpr int TSTR = TB + 1;
+constexpr int TL_VEC = 0, TL_ROW = TL_VEC + 2*NVX, TL_TILE = TL_ROW + NVX;
+constexpr int TEAM_LDS_WORDS = TEAMED ? TL_TILE + TB*TSTR : 1;
+
+template <bool T> struct WsRowT { typedef GlbRow type; };
+template <> struct WsRowT<true> { typedef TeamRow type; };
+typedef WsRowT<TEAMED>::type WsRow;
 
 struct Work {
-  real* lds;   // LDS base + lane (rows, then contact records)
-  real* glb;   // workspace base + env
-  long long nenv;
+  real* lds;   // LDS base + lane (rows, then contact records); team mode: the team's LDS
+  real* glb;   // workspace base + env (team mode: base of the env's contiguous block)
+  long long nenv;   // stride between the words of a record (team mode: 1)
   __device__ __forceinline__ LdsRow lrow(int r) const { return LdsRow{lds + r*RW*LANES}; }
-  __device__ __forceinline__ GlbRow grow(int r) const {
-    return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
+  template <bool T = TEAMED>
+  __device__ __forceinline__ typename WsRowT<T>::type grow(int r) const {
+    if constexpr (T) {
+      return TeamRow{glb + (long long)r*NV, glb + (long long)NEFC_MAX*NV + r};
+    } else {
+      return GlbRow{glb + (long long)(r - LDS_ROWS)*RW*nenv, nenv};
+    }
   }
   __device__ __forceinline__ GlbMat mat(int k) const {
     return GlbMat{glb + ((long long)WS_MAT + (long long)k*NM)*nenv, nenv};
@@ -610,6 +747,356 @@ template <> struct MatsT<true> {       // HBM workspace
   static __device__ __forceinline__ GlbMat local(real*, const Work& W, int k) { return W.mat(k); }
 };
 typedef MatsT<MAT_IN_WS> Mats;
+
+// ===========================================================================
+// Team algebra (team mode, big scenes).  Packed matrices live in the env's
+// workspace block with unit stride; a kinematic tree's diagonal block (<= TB
+// dofs) is worked on as a tile in the team's LDS.  Private vectors (x, y) are
+// replicated: every lane ends every function with the same values.
+// ===========================================================================
+constexpr int KPL = (TB + TEAM - 1)/TEAM;       // tile columns per lane
+static_assert(!TEAMED || MAT_IN_WS, "team mode is for scenes whose matrices live in the workspace");
+static_assert(!TEAMED || MAXTREEDOF <= TB, "team mode: a kinematic tree has at most TB dofs");
+
+#if defined(DMC_TEAM) && !defined(DMC_HOST_SHIM)
+DEV unsigned long long tballot(bool b) {
+  const unsigned long long w = __ballot(b);
+  if (TEAM == 64) return w;
+  return (w >> ((threadIdx.x/TEAM)*TEAM)) & ((1ull << TEAM) - 1);
+}
+DEV void tatomic_min(int* p, int v) { atomicMin(p, v); }
+#elif defined(DMC_TEAM)
+DEV unsigned long long tballot(bool b) {
+  unsigned long long x = b ? 1ull << tlane() : 0ull;
+  for (int m = TEAM/2; m > 0; m >>= 1) x |= txor(x, m);
+  return x;
+}
+DEV void tatomic_min(int* p, int v) {
+  int cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+#else
+DEV unsigned long long tballot(bool b) { return b ? 1ull : 0ull; }
+DEV void tatomic_min(int* p, int v) { if (v < *p) *p = v; }
+#endif
+DEV int tfirst_bit(unsigned long long m) { return __builtin_ctzll(m); }
+// first k >= lo that lane `tl` owns (k = tl mod TEAM)
+DEV int towned_from(int lo, int tl) { return lo + ((tl - lo) & (TEAM - 1)); }
+
+// tile <- A[s .. s+n-1][s .. row]; sixteen rows in flight
+template <class Mat>
+DEV void tile_load(real* T, const Mat& A, int s, int n) {
+  const int tl = tlane();
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    real a[16][KPL];
+    _Pragma("unroll")
+    for (int u = 0; u < 16; u++) {
+      const int ii = i0 + u;
+      _Pragma("unroll")
+      for (int m = 0; m < KPL; m++) {
+        const int k = tl + m*TEAM;
+        a[u][m] = (ii < n && k <= ii) ? A.get(tri(s + ii, s + k)) : R(0);
+      }
+    }
+    _Pragma("unroll")
+    for (int u = 0; u < 16; u++) {
+      const int ii = i0 + u;
+      _Pragma("unroll")
+      for (int m = 0; m < KPL; m++) {
+        const int k = tl + m*TEAM;
+        if (ii < n && k <= ii) T[ii*TSTR + k] = a[u][m];
+      }
+    }
+  }
+  tsync();
+}
+template <class Mat>
+DEV void tile_store(const Mat& A, const real* T, int s, int n) {
+  const int tl = tlane();
+  for (int ii = 0; ii < n; ii++)
+    for (int k = tl; k <= ii; k += TEAM) A.set(tri(s + ii, s + k), T[ii*TSTR + k]);
+  tsync();
+}
+// in place T = L L^T (lower part), the diagonal keeps the inverse pivots
+DEV int tile_factor(real* T, int n) {
+  const int tl = tlane();
+  int nbad = 0;
+  for (int j = 0; j < n; j++) {
+    real d = T[j*TSTR + j];
+    if (!(d >= DMC_MINVAL)) { d = DMC_MINVAL; nbad++; }
+    const real inv = rsqrt_(d);
+    tsync();                                  // every lane has read the pivot
+    for (int ii = j + 1 + tl; ii < n; ii += TEAM) T[ii*TSTR + j] *= inv;
+    if (tl == 0) T[j*TSTR + j] = inv;
+    tsync();
+    for (int ii = j + 1 + tl; ii < n; ii += TEAM) {
+      const real lij = T[ii*TSTR + j];
+      for (int k = j + 1; k <= ii; k++) T[ii*TSTR + k] -= lij*T[k*TSTR + j];
+    }
+    tsync();
+  }
+  return nbad;
+}
+// sum_k A[bi + k] B[bj + k], k in [k0, k1): eight loads of each in flight
+template <class Mat>
+DEV real env_dot2(const Mat& A, int bi, int bj, int k0, int k1) {
+  real t = 0;
+  int k = k0;
+  for (; k + 8 <= k1; k += 8) {
+    real a[8], b[8];
+    _Pragma("unroll") for (int u = 0; u < 8; u++) { a[u] = A.get(bi + k + u); b[u] = A.get(bj + k + u); }
+    _Pragma("unroll") for (int u = 0; u < 8; u++) t += a[u]*b[u];
+  }
+  for (; k < k1; k++) t += A.get(bi + k)*A.get(bj + k);
+  return t;
+}
+// rows of the tree [s, e] whose envelope starts left of it (a contact couples the
+// tree to an earlier one): their entries left of the tile, one row per lane
+template <class Mat>
+DEV void team_coupled_left(const Mat& F, const Mat& H, const int* lo, int s, int e) {
+  for (int i = s + tlane(); i <= e; i += TEAM) {
+    const int li = lo[i];
+    if (li >= s) continue;
+    const int bi = tri(i, 0);
+    for (int j = li; j < s; j++) {
+      const int lj = lo[j], bj = tri(j, 0);
+      const real t = H.get(bi + j) - env_dot2(F, bi, bj, li > lj ? li : lj, j);
+      F.set(bi + j, t*F.get(bj + j));
+    }
+  }
+  tsync();
+}
+// ... and what they take out of the tile
+template <class Mat>
+DEV void team_coupled_tile(real* T, const Mat& F, const int* lo, int s, int e) {
+  for (int i = s + tlane(); i <= e; i += TEAM) {
+    const int li = lo[i];
+    if (li >= s) continue;
+    for (int k = s; k <= i; k++) {
+      const int lk = lo[k];
+      if (lk >= s) continue;
+      T[(i - s)*TSTR + (k - s)] -= env_dot2(F, tri(i, 0), tri(k, 0), li > lk ? li : lk, s);
+    }
+  }
+  tsync();
+}
+// pending changes of the Hessian (ROW_FLIP = +-D) of the rows that touch the
+// tile [s, e], applied to the tile in LDS; returns whether there were any
+DEV bool team_tile_flips(real* T, const Work& W, int nefc, int s, int e) {
+  const int tl = tlane();
+  real* seg = W.lds + TL_ROW;
+  bool any = false;
+  for (int r0 = 0; r0 < nefc; r0 += TEAM) {
+    const int r = r0 + tl;
+    bool mine = false;
+    if (r < nefc) {
+      const auto rec = W.grow(r);
+      mine = rec.get(ROW_FLIP) != 0 && (int)rec.get(ROW_HI) >= s && (int)rec.get(ROW_LO) <= e;
+    }
+    unsigned long long m = tballot(mine);
+    while (m) {
+      const int b = tfirst_bit(m);
+      m &= m - 1;
+      any = true;
+      const auto rec = W.grow(r0 + b);
+      const real Ds = rec.get(ROW_FLIP);
+      const int lo = (int)rec.get(ROW_LO), hi = (int)rec.get(ROW_HI);
+      if (lo == hi) {                          // a joint limit: one diagonal entry
+        if (tl == 0) { const real v = rec.get(lo); T[(lo - s)*TSTR + (lo - s)] += Ds*v*v; }
+        tsync();
+        continue;
+      }
+      const int c0 = lo > s ? lo : s, c1 = hi < e ? hi : e;
+      for (int k = c0 + tl; k <= c1; k += TEAM) seg[k - s] = rec.get(k);
+      tsync();
+      for (int j = c0; j <= c1; j++) {
+        const real vj = seg[j - s];
+        if (vj == 0) continue;
+        const real sj = Ds*vj;
+        for (int k = c0 + tl; k <= j; k += TEAM) {
+          const real vk = seg[k - s];
+          if (vk != 0) T[(j - s)*TSTR + (k - s)] += sj*vk;
+        }
+      }
+      tsync();
+    }
+  }
+  return any;
+}
+// the same for the entries LEFT of the tiles: rows whose dofs lie in two trees.
+// `first`: the coupled rows' left parts start from zero (M has nothing there).
+template <class Mat>
+DEV void team_cross_flips(const Mat& H, const Work& W, int nefc, const int* hlo, bool first) {
+  const int tl = tlane();
+  bool coupled = false;
+  for (int i = 0; i < NV; i++) coupled |= hlo[i] < dof_treeroot[i];
+  if (!coupled) return;
+  if (first) {
+    for (int i = 0; i < NV; i++) {
+      const int s = dof_treeroot[i];
+      for (int k = hlo[i] + tl; k < s; k += TEAM) H.set(tri(i, k), R(0));
+    }
+    tsync();
+  }
+  real* seg = W.lds + TL_ROW;
+  for (int r0 = 0; r0 < nefc; r0 += TEAM) {
+    const int r = r0 + tl;
+    bool mine = false;
+    if (r < nefc) {
+      const auto rec = W.grow(r);
+      mine = rec.get(ROW_FLIP) != 0 &&
+             (int)rec.get(ROW_LO) < dof_treeroot[(int)rec.get(ROW_HI)];
+    }
+    unsigned long long m = tballot(mine);
+    while (m) {
+      const int b = tfirst_bit(m);
+      m &= m - 1;
+      const auto rec = W.grow(r0 + b);
+      const real Ds = rec.get(ROW_FLIP);
+      const int lo = (int)rec.get(ROW_LO), hi = (int)rec.get(ROW_HI);
+      for (int k = lo + tl; k <= hi; k += TEAM) seg[k] = rec.get(k);
+      tsync();
+      for (int j = lo; j <= hi; j++) {
+        const real vj = seg[j];
+        const int sj = dof_treeroot[j];
+        if (vj == 0 || sj <= lo) continue;
+        const real dj = Ds*vj;
+        for (int k = lo + tl; k < sj; k += TEAM) {
+          const real vk = seg[k];
+          if (vk != 0) H.set(tri(j, k), H.get(tri(j, k)) + dj*vk);
+        }
+      }
+      tsync();
+    }
+  }
+}
+// dst <- Cholesky factor of (src [+ h*damping on the diagonal] [+ pending row
+// changes]), tree by tree.  `flips`: the Newton Hessian -- the changed tiles
+// also go back to `H`, rows coupled to an earlier tree take their left parts from H.
+template <class Mat>
+DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* lo,
+                    real damping_h, bool flips, bool first, int nefc, const Mat& H) {
+  real* T = W.lds + TL_TILE;
+  const int tl = tlane();
+  int nbad = 0;
+  if (flips) team_cross_flips(H, W, nefc, lo, first);
+  for (int t = 0; t < NDTREE; t++) {
+    const int s = dtree_lo[t], e = dtree_hi[t], n = e - s + 1;
+    tile_load(T, src, s, n);
+    if (damping_h != 0) {
+      for (int ii = tl; ii < n; ii += TEAM) T[ii*TSTR + ii] += damping_h*R(dof_damping[s + ii]);
+      tsync();
+    }
+    if (flips) {
+      const bool changed = team_tile_flips(T, W, nefc, s, e);
+      if (changed || first) tile_store(H, T, s, n);
+      bool coupled = false;
+      for (int i = s; i <= e; i++) coupled |= lo[i] < s;
+      if (coupled) {
+#if defined(DMC_HOST_SHIM) && defined(DMC_TEAM_TRACE)
+        if (tl == 0) fprintf(stderr, "coupled tree %d first %d\n", t, (int)first);
+#endif
+        team_coupled_left(dst, H, lo, s, e);
+        team_coupled_tile(T, dst, lo, s, e);
+      }
+    }
+    nbad += tile_factor(T, n);
+    tile_store(dst, T, s, n);
+  }
+  return nbad;
+}
+// x <- F^-T F^-1 x inside the envelope `lo` (x replicated before and after)
+template <class Mat>
+DEV void team_solve(real* x, const Mat& F, const int* lo) {
+  const int tl = tlane();
+  for (int i0 = 0; i0 < NV; i0 += 8) {
+    real a[8], dg[8];
+    int kk[8];
+    _Pragma("unroll")
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u;
+      kk[u] = 0; a[u] = 0; dg[u] = 0;
+      if (i < NV) {
+        kk[u] = towned_from(lo[i], tl);
+        a[u] = kk[u] < i ? F.get(tri(i, kk[u])) : R(0);
+        dg[u] = F.get(tri(i, i));
+      }
+    }
+    _Pragma("unroll")
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u;
+      if (i < NV) {
+        real p = kk[u] < i ? a[u]*x[kk[u]] : R(0);
+        for (int k = kk[u] + TEAM; k < i; k += TEAM) p += F.get(tri(i, k))*x[k];
+        x[i] = (x[i] - tsum(p))*dg[u];
+      }
+    }
+  }
+  // backward: lane k mod TEAM carries entry k; row i hands its value to the team
+  for (int i1 = NV - 1; i1 >= 0; i1 -= 8) {
+    real a[8], dg[8];
+    int kk[8];
+    _Pragma("unroll")
+    for (int u = 0; u < 8; u++) {
+      const int i = i1 - u;
+      kk[u] = 0; a[u] = 0; dg[u] = 0;
+      if (i >= 0) {
+        kk[u] = towned_from(lo[i], tl);
+        a[u] = kk[u] < i ? F.get(tri(i, kk[u])) : R(0);
+        dg[u] = F.get(tri(i, i));
+      }
+    }
+    _Pragma("unroll")
+    for (int u = 0; u < 8; u++) {
+      const int i = i1 - u;
+      if (i >= 0) {
+        const real xi = tget(x[i], i & (TEAM - 1))*dg[u];
+        x[i] = xi;
+        if (kk[u] < i) x[kk[u]] -= a[u]*xi;
+        for (int k = kk[u] + TEAM; k < i; k += TEAM) x[k] -= F.get(tri(i, k))*xi;
+      }
+    }
+  }
+}
+// y = A x (A symmetric, lower part stored inside the envelope `lo`)
+template <class Mat>
+DEV void team_symv(const Work& W, real* y, const Mat& A, const real* x, const int* lo) {
+  const int tl = tlane();
+  real* buf = W.lds + TL_VEC;
+  for (int k = tl; k < NV; k += TEAM) buf[k] = 0;      // column sums of the owned entries
+  for (int i0 = 0; i0 < NV; i0 += 8) {
+    real a[8], dg[8];
+    int kk[8];
+    _Pragma("unroll")
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u;
+      kk[u] = 0; a[u] = 0; dg[u] = 0;
+      if (i < NV) {
+        kk[u] = towned_from(lo[i], tl);
+        a[u] = kk[u] < i ? A.get(tri(i, kk[u])) : R(0);
+        dg[u] = A.get(tri(i, i));
+      }
+    }
+    _Pragma("unroll")
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u;
+      if (i < NV) {
+        const real xi = x[i];
+        real p = 0;
+        if (kk[u] < i) { p = a[u]*x[kk[u]]; buf[kk[u]] += a[u]*xi; }
+        for (int k = kk[u] + TEAM; k < i; k += TEAM) {
+          const real aik = A.get(tri(i, k));
+          p += aik*x[k];
+          buf[k] += aik*xi;
+        }
+        y[i] = tsum(p) + dg[u]*xi;
+      }
+    }
+  }
+  tsync();
+  for (int k = 0; k < NV; k++) y[k] += buf[k];
+  tsync();
+}
 
 // ---------------------------------------------------------------------------
 // position stage: kinematics, centre-of-mass frame, composite inertia
@@ -804,6 +1291,26 @@ DEV void crb_factor(Env& E, const Work& W) {
     if (body_parentid[i] > 0)
       DMC_UNROLL
       for (int k = 0; k < 10; k++) crb[10*body_parentid[i] + k] += crb[10*i + k];
+  if (TEAMED) {
+    // rows of M inside the envelope: cleared by the team (lanes along a row), then
+    // one dof per lane writes its diagonal and ancestor entries
+    const int tl = tlane();
+    for (int i = 0; i < NV; i++)
+      for (int j = dof_treeroot[i] + tl; j <= i; j += TEAM) M.set(tri(i, j), 0);
+    tsync();
+    for (int i = tl; i < NV; i += TEAM) {
+      real buf[6];
+      mul_inert_vec(buf, crb + 10*dof_bodyid[i], E.cdof + 6*i);
+      M.set(tri(i, i), dot6(E.cdof + 6*i, buf) + R(dof_armature[i]));
+      for (int a = 0; a < dof_anc_len[i]; a++) {
+        const int j = dof_anc[i*MAXCHAIN + a];
+        M.set(tri(i, j), dot6(E.cdof + 6*j, buf));
+      }
+    }
+    tsync();
+    if (team_factor(W, L, M, E.mlo, R(0), false, false, 0, L)) E.warn |= WARN_INERTIA;
+    return;
+  }
   if (MAT_IN_WS) {
     for (int i = 0; i < NV; i++)
       for (int j = dof_treeroot[i]; j <= i; j++) M.set(tri(i, j), 0);
@@ -965,7 +1472,8 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
   }
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qacc_smooth[i] = E.qfrc_smooth[i];
-  if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
+  if (TEAMED) team_solve(E.qacc_smooth, Mats::L(E, W), E.mlo);
+  else if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
   else chol_solve(E.qacc_smooth, Mats::L(E, W));
 }
 
@@ -1666,9 +2174,74 @@ DEV void write_contact(const Rec& rec, int p, const RawCon& c) {
   rec.set(10, (real)p);
 }
 
+// Team mode: the narrowphase runs one pair per lane, a chunk of TEAM pairs at a
+// time; the contacts of a chunk are appended in pair order (exclusive scan of the
+// per-lane counts), so the contact list equals the serial loop's.
+DEV real tmaxr(real x) {
+  for (int m = TEAM/2; m > 0; m >>= 1) { const real y = txor(x, m); x = y > x ? y : x; }
+  return x;
+}
+DEV void detect_contacts_team(Env& E, const Work& W) {
+  const int tl = tlane();
+  const auto G = PoseSrc<MAT_IN_WS>::make(W, nullptr);
+  geom_poses(E, G);              // (every lane writes the same mirror)
+  tsync();
+  constexpr int NTREEX = NTREE > 0 ? NTREE : 1;
+  real tcen[NTREEX*3], trad[NTREEX];
+  for (int t = 0; t < NTREE; t++) {
+    trad[t] = 0;
+    for (int k = 0; k < 3; k++) tcen[3*t + k] = E.subtree_com[3*root_body[t] + k];
+  }
+  for (int g = tl; g < NGEOM; g += TEAM) {
+    const int t = geom_tree[g];
+    if (t < 0) continue;
+    real d2 = 0;
+    for (int k = 0; k < 3; k++) {
+      const real d = G.get(12*g + k) - tcen[3*t + k];
+      d2 += d*d;
+    }
+    const real reach = sqrt(d2) + R(geom_rbound[g]);
+    if (reach > trad[t]) trad[t] = reach;
+  }
+  for (int t = 0; t < NTREE; t++) trad[t] = tmaxr(trad[t]);
+  auto far_apart = [&](int p) {
+    const int t1 = pair_tree1[p], t2 = pair_tree2[p];
+    if (!(t1 >= 0 && t2 >= 0 && t1 != t2)) return false;
+    real d2 = 0;
+    for (int k = 0; k < 3; k++) {
+      const real d = tcen[3*t1 + k] - tcen[3*t2 + k];
+      d2 += d*d;
+    }
+    const real reach = trad[t1] + trad[t2] + R(pair_margin[p]);
+    return d2 > reach*reach;
+  };
+  int p0 = 0;
+  while (p0 < NPAIR) {
+    if (NTREE > 1 && pair_margin[p0] == 0 && far_apart(p0)) { p0 += pair_run[p0]; continue; }
+    const int p = p0 + tl;
+    RawCon rc[4];
+    int mask = 0;
+    if (p < NPAIR && !(NTREE > 1 && far_apart(p))) mask = collide_pair(G, p, rc);
+    int cnt = 0;
+    for (int c = 0; c < 4; c++) cnt += (mask >> c) & 1;
+    int total;
+    int k = E.ncon + tscan(cnt, total);
+    for (int c = 0; c < 4; c++) {
+      if (!((mask >> c) & 1)) continue;
+      if (k < NCON_MAX) write_contact(W.gcon(k), p, rc[c]);
+      k++;
+    }
+    if (E.ncon + total > NCON_MAX) { E.warn |= WARN_CONTACTFULL; E.ncon = NCON_MAX; }
+    else E.ncon += total;
+    p0 += TEAM;
+  }
+  tsync();
+}
+
 // phase 1: narrowphase over the static pair list -> compact contact list
 DEV void detect_contacts(Env& E, const Work& W) {
   if (DISABLEFLAGS & (DSBL_CONTACT | DSBL_CONSTRAINT)) return;
+  if (TEAMED) { detect_contacts_team(E, W); return; }
   real Garr[MAT_IN_WS ? 1 : NGEOM*12];
   const auto G = PoseSrc<MAT_IN_WS>::make(W, Garr);
   geom_poses(E, G);
@@ -1849,8 +2422,32 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
   if (PLANAR_MERGE && merged) rec.set(10, (real)(p + MERGE_STRIDE*merged));
 }
 
+static_assert(!(TEAMED && PLANAR_MERGE), "team mode: no merged pyramid rows");
+// rows a contact record will push (team mode: known before they are written)
+template <class Rec>
+DEV int rows_of_contact_count(const Rec& rec) {
+  const int p = (int)rec.get(10);
+  if (rec.get(9) >= pair_includemargin[p]) return 0;
+  const int dim = pair_dim[p];
+  return dim == 1 ? 1 : 2*(dim - 1);
+}
 DEV void contact_rows(Env& E, const Work& W) {
   detect_contacts(E, W);
+  if (TEAMED) {
+    // one contact per lane; the rows keep the serial order (exclusive scan of the counts)
+    const int tl = tlane();
+    for (int k0 = 0; k0 < E.ncon; k0 += TEAM) {
+      const int k = k0 + tl;
+      const int mine = k < E.ncon ? rows_of_contact_count(W.gcon(k)) : 0;
+      int total;
+      const int first = E.nefc, at = tscan(mine, total);
+      if (mine > 0) { E.nefc = first + at; rows_of_contact(E, W, W.gcon(k)); }
+      E.warn = tor(E.warn);
+      E.nefc = first + total < NEFC_MAX ? first + total : NEFC_MAX;
+    }
+    tsync();
+    return;
+  }
   const int n1 = E.ncon < LDS_CONS ? E.ncon : LDS_CONS;
   for (int k = 0; k < n1; k++) rows_of_contact(E, W, W.lcon(k));
   if (LDS_CONS < NCON_MAX)
@@ -2083,6 +2680,185 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
   E.iters = iter;
 }
 
+// Team-mode Newton solver: the algorithm of solve_newton() with the passes over
+// the rows run one row per lane, the Hessian kept and factored tile by tile
+// (team_factor) and the sums over rows and dofs taken as team sums.
+DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
+  real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], fc[NVX];
+  const auto M = Mats::M(E, W);
+  const auto H = Mats::local(nullptr, W, MAT_H);
+  const auto F = Mats::L(E, W);
+  const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
+  const int nefc = E.nefc;
+  const int tl = tlane();
+  // envelope of the Hessian: M's, widened by the rows whose dofs lie in two trees
+  {
+    for (int i = 0; i < NV; i++) E.hlo[i] = dof_treeroot[i];
+    bool cross = false;
+    for (int r = tl; r < nefc; r += TEAM) {
+      const auto rec = W.grow(r);
+      cross |= (int)rec.get(ROW_LO) < dof_treeroot[(int)rec.get(ROW_HI)];
+    }
+    if (tany(cross)) {
+      int* hl = reinterpret_cast<int*>(W.lds + TL_VEC);
+      for (int i = tl; i < NV; i += TEAM) hl[i] = dof_treeroot[i];
+      tsync();
+      for (int r = tl; r < nefc; r += TEAM) {
+        const auto rec = W.grow(r);
+        const int lo = (int)rec.get(ROW_LO), hi = (int)rec.get(ROW_HI);
+        if (!(lo < dof_treeroot[hi])) continue;
+        for (int j = lo + 1; j <= hi; j++)
+          if (rec.get(j) != 0) tatomic_min(hl + j, lo);
+      }
+      tsync();
+      for (int i = 0; i < NV; i++) E.hlo[i] = hl[i];
+      tsync();
+    }
+    env_last_rows(E.hhi, E.hlo);
+  }
+  team_symv(W, Ma, M, E.qacc, E.mlo);
+  real improvement = 0, alpha_prev = 0;
+  int iter = 0;
+  for (;; iter++) {
+    // pass A: one row per lane
+    for (int i = 0; i < NV; i++) fc[i] = 0;
+    bool changed = false;
+    for (int r = tl; r < nefc; r += TEAM) {
+      const auto rec = W.grow(r);
+      real jar = rec.get(ROW_JAR);
+      const real jv = rec.get(ROW_JV), D = rec.get(ROW_D);
+      bool was = false;
+      if (iter > 0) {
+        was = jar < 0;
+        jar += alpha_prev*jv;
+        rec.set(ROW_JAR, jar);
+      } else if (start_smooth) {
+        jar = jv;
+        rec.set(ROW_JAR, jar);
+      }
+      const bool now = jar < 0;
+      if (now) {
+        const real f = -D*jar;
+        const int jlo = (int)rec.get(ROW_LO), jhi = (int)rec.get(ROW_HI);
+        int j = jlo;
+        for (; j + 8 <= jhi + 1; j += 8) {
+          real a[8];
+          _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = rec.get(j + u);
+          _Pragma("unroll") for (int u = 0; u < 8; u++) fc[j + u] += a[u]*f;
+        }
+        for (; j <= jhi; j++) fc[j] += rec.get(j)*f;
+      }
+      rec.set(ROW_FLIP, now != was ? (now ? D : -D) : R(0));
+      changed |= now != was;
+    }
+    changed = tany(changed);
+    tsync();                      // ROW_FLIP / ROW_JAR are read by other lanes from here on
+    real gn = 0;
+    for (int i = 0; i < NV; i++) {
+      E.qfrc_constraint[i] = tsum(fc[i]);
+      grad[i] = Ma[i] - E.qfrc_smooth[i] - E.qfrc_constraint[i];
+      gn += grad[i]*grad[i];
+    }
+    const bool converged = DMC_F32_RULES && iter > 0 && !changed &&
+                           fabs(alpha_prev - 1) < R(1e-3);
+    if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
+    if (iter >= ITERATIONS) break;
+    for (int i = 0; i < NV; i++) search[i] = -grad[i];
+    if (iter == 0) team_factor(W, F, M, E.hlo, R(0), true, true, nefc, H);
+    else team_factor(W, F, H, E.hlo, R(0), true, false, nefc, H);
+    team_solve(search, F, E.hlo);
+    real sn = 0;
+    for (int i = 0; i < NV; i++) sn += search[i]*search[i];
+    sn = sqrt(sn);
+    alpha_prev = 0;
+    if (sn < DMC_MINVAL) break;
+    const real gtol = tol*R(0.01)*sn/scale;
+    team_symv(W, Mv, M, search, E.mlo);
+    real q1 = 0, q2 = 0;
+    for (int i = 0; i < NV; i++) {
+      q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
+      q2 += R(0.5)*search[i]*Mv[i];
+    }
+    // pass B: Jv and the line-search sums at alpha = 0 (and, fp32, at alpha = 1)
+    LsPoint p0, p, best;
+    {
+      real d0 = 0, d1 = 0, c1 = 0, e0 = 0, e1 = 0;
+      for (int r = tl; r < nefc; r += TEAM) {
+        const auto rec = W.grow(r);
+        const int jlo = (int)rec.get(ROW_LO), jhi = (int)rec.get(ROW_HI);
+        real sacc = 0;
+        int j = jlo;
+        for (; j + 8 <= jhi + 1; j += 8) {
+          real a[8];
+          _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = rec.get(j + u);
+          _Pragma("unroll") for (int u = 0; u < 8; u++) sacc += a[u]*search[j + u];
+        }
+        for (; j <= jhi; j++) sacc += rec.get(j)*search[j];
+        rec.set(ROW_JV, sacc);
+        const real x0 = rec.get(ROW_JAR), D = rec.get(ROW_D);
+        const real Dv = D*sacc;
+        if (x0 < 0) { d0 += Dv*x0; d1 += Dv*sacc; }
+        if (DMC_F32_RULES) {
+          const real x = x0 + sacc;
+          const real a = x < 0 ? x : R(0), a0 = x0 < 0 ? x0 : R(0);
+          c1 += R(0.5)*D*(a*a - a0*a0);
+          if (x < 0) { e0 += Dv*x; e1 += Dv*sacc; }
+        }
+      }
+      d0 = tsum(d0) + q1; d1 = tsum(d1) + 2*q2;
+      p0.alpha = 0; p0.dcost = 0; p0.d0 = d0;
+      p0.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+      p.alpha = 1; p.dcost = q2 + q1; p.d0 = 2*q2 + q1; p.d1 = 2*q2;
+      if (DMC_F32_RULES) {
+        p.dcost += tsum(c1); p.d0 += tsum(e0); p.d1 += tsum(e1);
+      }
+      p.d1 = p.d1 > DMC_MINVAL ? p.d1 : DMC_MINVAL;
+    }
+    tsync();
+    if (!(p0.d0 < 0)) break;
+    best = p0;
+    real lo = 0, hi = 0, a = DMC_F32_RULES ? R(1) : -p0.d0/p0.d1;
+    bool have_hi = false;
+    const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
+    for (int it = 0; it < DMC_LS_MAXIT; it++) {
+      if (!(DMC_F32_RULES && it == 0)) {
+        real dcost = 0, d0 = 0, d1 = 0;
+        for (int r = tl; r < nefc; r += TEAM) {
+          const auto rec = W.grow(r);
+          const real x0 = rec.get(ROW_JAR), v = rec.get(ROW_JV), D = rec.get(ROW_D);
+          const real x = x0 + a*v;
+          const real xa = x < 0 ? x : R(0), xa0 = x0 < 0 ? x0 : R(0);
+          dcost += R(0.5)*D*(xa*xa - xa0*xa0);
+          if (x < 0) { d0 += D*x*v; d1 += D*v*v; }
+        }
+        p.alpha = a;
+        p.dcost = tsum(dcost) + a*a*q2 + a*q1;
+        p.d0 = tsum(d0) + 2*a*q2 + q1;
+        d1 = tsum(d1) + 2*q2;
+        p.d1 = d1 > DMC_MINVAL ? d1 : DMC_MINVAL;
+      }
+      if (p.dcost < best.dcost) best = p;
+      if (fabs(p.d0) < dtol) break;
+      if (p.d0 < 0) lo = a; else { hi = a; have_hi = true; }
+      real an = a - p.d0/p.d1;
+      if (have_hi) {
+        if (!(an > lo && an < hi)) an = R(0.5)*(lo + hi);
+        if (hi - lo < R(1e-6)*hi) break;
+      } else if (an <= lo) {
+        an = 2*a;
+      }
+      a = an;
+    }
+    const real alpha = best.alpha;
+    if (alpha == 0) break;
+    improvement = -best.dcost;
+    for (int i = 0; i < NV; i++) { E.qacc[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
+    alpha_prev = alpha;
+  }
+  E.iters = iter;
+}
+
+
 // ---------------------------------------------------------------------------
 // touch sensors (mjSENS_TOUCH in mj_sensorAcc): sum of the normal forces of the
 // contacts that involve the sensor site's body and whose force ray, cast from
@@ -2229,12 +3005,35 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
     real Ma[NVX], cw = 0, cs = 0;
     if (try_warm) {
-      if (MAT_IN_WS) symv_env(Ma, Mats::M(E, W), E.warm, LoTree{});
+      if (TEAMED) team_symv(W, Ma, Mats::M(E, W), E.warm, E.mlo);
+      else if (MAT_IN_WS) symv_env(Ma, Mats::M(E, W), E.warm, LoTree{});
       else symv(Ma, Mats::M(E, W), E.warm);
       DMC_UNROLL
       for (int i = 0; i < NV; i++)
         cw += R(0.5)*(Ma[i] - E.qfrc_smooth[i])*(E.warm[i] - E.qacc_smooth[i]);
     }
+    if (TEAMED) {                       // one row per lane
+      real rw = 0, rs = 0;
+      for (int r = tlane(); r < E.nefc; r += TEAM) {
+        const auto rec = W.grow(r);
+        const int jlo = (int)rec.get(ROW_LO), jhi = (int)rec.get(ROW_HI);
+        const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
+        real jw = 0, js = 0;
+        int j = jlo;
+        for (; j + 8 <= jhi + 1; j += 8) {
+          real a[8];
+          _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = rec.get(j + u);
+          _Pragma("unroll") for (int u = 0; u < 8; u++) { jw += a[u]*E.warm[j + u]; js += a[u]*E.qacc_smooth[j + u]; }
+        }
+        for (; j <= jhi; j++) { const real a = rec.get(j); jw += a*E.warm[j]; js += a*E.qacc_smooth[j]; }
+        jw -= aref; js -= aref;
+        if (jw < 0) rw += R(0.5)*D*jw*jw;
+        if (js < 0) rs += R(0.5)*D*js*js;
+        rec.set(ROW_JAR, jw); rec.set(ROW_JV, js);
+      }
+      cw += tsum(rw); cs += tsum(rs);
+      tsync();
+    } else
     for_rows(W, E.nefc, [&](auto rec) {
       real row[NVX];
       const int jlo = row_lo(rec), jhi = row_hi(rec);
@@ -2252,7 +3051,8 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     const bool use_warm = try_warm && !(cw > cs);
     DMC_UNROLL
     for (int i = 0; i < NV; i++) E.qacc[i] = use_warm ? E.warm[i] : E.qacc_smooth[i];
-    solve_newton(E, W, tol, !use_warm);
+    if (TEAMED) solve_newton_team(E, W, tol, !use_warm);
+    else solve_newton(E, W, tol, !use_warm);
   }
   FPROF(5);
   if (NTOUCH > 0) touch_sensors(E, W);
@@ -2372,6 +3172,11 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
       real Areg[MAT_REGS];
       const auto M = Mats::M(E, W);
       const LaneMat A = Mats::local(Areg, W, MAT_A);
+      if (TEAMED) {
+        for (int i = 0; i < NV; i++) qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
+        team_factor(W, A, M, E.mlo, h, false, false, 0, A);
+        team_solve(qacc, A, E.mlo);
+      } else {
       if (MAT_IN_WS) copy_env(A, M, LoTree{}, LoTree{});
       else {
         DMC_UNROLL
@@ -2388,6 +3193,7 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
       } else {
         chol_factor(A);
         chol_solve(qacc, A);
+      }
       }
     } else {
       DMC_UNROLL
@@ -2754,6 +3560,7 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
 }
 DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
   const long long n = a.nenv;
+  if (TEAMED && tlane() != 0) return;      // every lane holds the same state
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) a.qpos[i*n + e] = E.qpos[i];
   DMC_UNROLL
@@ -2778,13 +3585,14 @@ DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
 // envs of a workgroup are one contiguous chunk, so they are transposed through
 // LDS (the solver's row store is dead by now) and written as full wave-wide
 // coalesced stores.  Other layouts (explicit strides) are written directly.
-constexpr bool OBS_STAGE_FITS = LDS_WORDS >= LANES*(NOBS > 0 ? NOBS : 1);
+constexpr bool OBS_STAGE_FITS = !TEAMED && LDS_WORDS >= LANES*(NOBS > 0 ? NOBS : 1);
 
 DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
                        real* lds_base) {
   const long long n = a.nenv;
   real obs[NOBS > 0 ? NOBS : 1];
   const real rew = task_outputs(E, a, obs);
+  if (TEAMED && tlane() != 0) return;
   if (OBS_STAGE_FITS && a.obs_sk == 1 && a.obs_se == NOBS) {
     const int lane = threadIdx.x;
     DMC_UNROLL
@@ -2839,8 +3647,8 @@ DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
 #endif
 extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_step(DmcArgs a) {
-  const int e = blockIdx.x*blockDim.x + threadIdx.x;
-  if (e >= a.nenv) return;
+  const int e = (int)((blockIdx.x*blockDim.x + threadIdx.x)/TEAM);
+  if (e >= a.nenv) return;                 // (team mode: a team leaves together)
   Env E;
   real time;
   load_env(E, a, e, time);
@@ -2863,8 +3671,10 @@ dmc_step(DmcArgs a) {
     DMC_UNROLL
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
-  __shared__ real lds_rows[LDS_WORDS];
-  Work W = {lds_rows + threadIdx.x, a.ws + e, n};
+  __shared__ real lds_rows[TEAMED ? TEAM_LDS_WORDS*(LANES/TEAM) : LDS_WORDS];
+  const Work W = TEAMED
+      ? Work{lds_rows + (threadIdx.x/TEAM)*TEAM_LDS_WORDS, a.ws + (long long)e*WS_WORDS, 1}
+      : Work{lds_rows + threadIdx.x, a.ws + e, n};
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
   for (int s = 0; s < a.nsub; s++)
     physics_step(E, W, time, tol, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
@@ -2891,16 +3701,18 @@ dmc_step(DmcArgs a) {
 // observation / reward / sensors of the current state (reset, after_reset)
 extern "C" __global__ void __launch_bounds__(LANES, DMC_WAVES_PER_EU)
 dmc_observe(DmcArgs a) {
-  const int e = blockIdx.x*blockDim.x + threadIdx.x;
-  if (e >= a.nenv) return;
+  const int e = (int)((blockIdx.x*blockDim.x + threadIdx.x)/TEAM);
+  if (e >= a.nenv) return;                 // (team mode: a team leaves together)
   Env E;
   real time;
   load_env(E, a, e, time);
   const long long n = a.nenv;
   DMC_UNROLL
   for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
-  __shared__ real lds_rows[LDS_WORDS];
-  Work W = {lds_rows + threadIdx.x, a.ws + e, n};
+  __shared__ real lds_rows[TEAMED ? TEAM_LDS_WORDS*(LANES/TEAM) : LDS_WORDS];
+  const Work W = TEAMED
+      ? Work{lds_rows + (threadIdx.x/TEAM)*TEAM_LDS_WORDS, a.ws + (long long)e*WS_WORDS, 1}
+      : Work{lds_rows + threadIdx.x, a.ws + e, n};
   if (NTOUCH > 0) {
     // acceleration-stage sensors need the constraint forces: the reference's
     // after_reset runs mj_forward with actuation disabled (engine.py:283-295);
@@ -2947,7 +3759,7 @@ struct Rng {
 // flags bit3: only redraw envs whose stats[ncon] > 0 (humanoid rejection loop)
 extern "C" __global__ void __launch_bounds__(64)
 dmc_init_episode(DmcArgs a) {
-  const int e = blockIdx.x*blockDim.x + threadIdx.x;
+  const int e = blockIdx.x*blockDim.x + threadIdx.x;   // one env per lane in every build
   if (e >= a.nenv) return;
   const long long n = a.nenv;
   if ((a.flags & 8) && a.stats[sidx(0, e, n, 3)] == 0) return;
@@ -3040,7 +3852,8 @@ dmc_init_episode(DmcArgs a) {
 extern "C" __device__ const int dmc_info[20] = {
     1 /*abi*/, (int)sizeof(real), NQ, NV, NU, NBODY, NOBS, NSENSORDATA,
     (WS_WORDS > 0 ? WS_WORDS : 1) /*workspace reals per env*/, TASK, NCON_MAX, NEFC_MAX,
-    INTEGRATOR, NPAIR, LANES /*envs (= threads) per workgroup of dmc_step/dmc_observe;
+    INTEGRATOR, NPAIR, LANES/TEAM /*envs per workgroup of dmc_step/dmc_observe (= its
+                                threads unless a team of lanes shares an env);
                                 the workspace is sized for the batch rounded up to this*/,
     DMC_ENV_MAJOR /*0: state fields are [k][env]*/, NTASKDATA,
     LANES /*threads per workgroup*/, 0, 0};
