@@ -123,9 +123,11 @@ def _ego(vec, xmat):
 
 
 class Physics(engine.Physics):
-  """The whole pitch as one model, one env per lane, generic (rolled) loops."""
+  """The whole pitch as one model; one wavefront per pitch ("team" build of
+  csrc/dmc_kernels.hip: generic loops, the matrices of a pitch in the HBM
+  workspace and one kinematic tree's block at a time in LDS)."""
 
-  _BUILD_MODE = 'rolled'
+  _BUILD_MODE = 'team'
 
 
 class Task(control.Task):

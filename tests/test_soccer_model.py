@@ -356,14 +356,16 @@ def test_single_walker_fp64_at_full_contact_capacity():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['team', 'rolled'])
 @pytest.mark.parametrize('quiet', [True, False])
-def test_two_by_two_pitch_on_device_matches_oracle(quiet):
+def test_two_by_two_pitch_on_device_matches_oracle(quiet, mode):
   """BASELINE configs[4]: the 2v2 pitch (nq 259, nv 254, nu 224; four CMU
-  humanoids, regulation ball, two goal frames) as ONE model on the device: the
-  one-env-per-lane kernel, generic loops, the four packed 254 x 254 matrices and
-  the geom-pose mirror of each pitch in the HBM workspace.  fp64 per step
-  against the oracle at full contact capacity, with walker-pitch, walker-ball
-  and (quiet=False) walker-walker / self contacts; fp32 statistics."""
+  humanoids, regulation ball, two goal frames) as ONE model on the device, the
+  four packed 254 x 254 matrices and the geom-pose mirror of each pitch in the
+  HBM workspace: `team` = one wavefront per pitch (what `soccer.load` runs),
+  `rolled` = one pitch per lane.  fp64 per step against the oracle at full
+  contact capacity, with walker-pitch, walker-ball and (quiet=False)
+  walker-walker / self contacts; fp32 statistics."""
   from dm_control_amd import build, wrapper as W
   m = _pitch_model(quiet)
   assert (m.nq, m.nv, m.nu) == (259, 254, 224)
@@ -372,20 +374,20 @@ def test_two_by_two_pitch_on_device_matches_oracle(quiet):
   qpos, qvel = _pitch_states(m, nenv, rs)
   if not quiet:                   # two players into each other
     qpos[:, 63:65] = qpos[:, 0:2] + [0.25, 0.1]
-  hm = W.HipModel(build.build_model(m, 0, 'f64', ncon_max=64, mode='rolled'))
+  hm = W.HipModel(build.build_model(m, 0, 'f64', ncon_max=64, mode=mode))
   hb = W.HipBatch(hm, nenv)
   e, rows = _teacher_forced(m, hb, qpos, qvel, 5, np.random.RandomState(1), W)
-  print('OBSERVED 2v2 pitch f64 (quiet=%s): per-step max %.2e; ncon up to %d, %d rows in all'
-        % (quiet, e.max(), _teacher_forced.max_ncon, rows))
+  print('OBSERVED 2v2 pitch f64 %s (quiet=%s): per-step max %.2e; ncon up to %d, %d rows in all'
+        % (mode, quiet, e.max(), _teacher_forced.max_ncon, rows))
   assert not hb.read(W.FIELD_WARN).any()
   assert _teacher_forced.max_ncon >= 30 and rows > nenv*5*250
   assert e.max() <= 1e-9, e.max()
   hb.free()
-  hm32 = W.HipModel(build.build_model(m, 0, 'f32', ncon_max=64, mode='rolled'))
+  hm32 = W.HipModel(build.build_model(m, 0, 'f32', ncon_max=64, mode=mode))
   hb = W.HipBatch(hm32, nenv)
   e32, _ = _teacher_forced(m, hb, qpos, qvel, 5, np.random.RandomState(1), W)
-  print('OBSERVED 2v2 pitch f32 (quiet=%s): per-step median %.2e p90 %.2e max %.2e'
-        % (quiet, np.median(e32), np.percentile(e32, 90), e32.max()))
+  print('OBSERVED 2v2 pitch f32 %s (quiet=%s): per-step median %.2e p90 %.2e max %.2e'
+        % (mode, quiet, np.median(e32), np.percentile(e32, 90), e32.max()))
   assert np.median(e32) <= 2e-4 and np.isfinite(e32).all()
   hb.free()
 

@@ -1,5 +1,6 @@
 """Stage profile of one control step of the 2v2 pitch (-DDMC_STEP_PROFILE build):
-mean / max over the pitches of the time per stage of forward(), 5 substeps."""
+mean / max over the pitches of the time per stage of forward(), 5 substeps.
+usage: pitch_profile.py quiet|loud [--team] [--f64] [--build-only]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -7,7 +8,9 @@ import numpy as np
 import test_soccer_model as S
 from dm_control_amd import build, wrapper as W
 m = S._pitch_model(sys.argv[1] == 'quiet')
-path = build.build_model(m, 0, 'f32', ncon_max=64, mode='rolled', extra_flags=('-DDMC_STEP_PROFILE=1',))
+MODE = 'team' if '--team' in sys.argv else 'rolled'
+PREC = 'f64' if '--f64' in sys.argv else 'f32'
+path = build.build_model(m, 0, PREC, ncon_max=64, mode=MODE, extra_flags=('-DDMC_STEP_PROFILE=1',))
 if '--build-only' in sys.argv:
   print(os.path.basename(path)); sys.exit(0)
 hm = W.HipModel(path)
@@ -27,7 +30,7 @@ hb.step_host(None, 5)
 ms, n = hb.timer_stop()
 prof = hb.read(W.FIELD_XPOS)[:8].astype(np.float64)/100.0     # us (100 MHz)
 names = ['kinematics+com', 'crb+factor M', 'com_vel+smooth', 'limit rows', 'contact rows', 'warm start+Newton', '-', '-']
-print('B=%d: %.1f ms per control step' % (B, ms/n))
+print('%s %s B=%d: %.2f ms per control step' % (MODE, PREC, B, ms/n))
 for k in range(6):
   print('  %-20s mean %9.1f us  max %9.1f us' % (names[k], prof[k].mean(), prof[k].max()))
 print('  sum of stages mean %.1f ms (x lanes run in lock step: a wave takes its slowest lane)' % (prof[:6].sum(axis=0).mean()/1e3))
