@@ -677,8 +677,12 @@ enum { MAT_M = 0, MAT_L = 1, MAT_H = 2, MAT_A = 3 };
 // matrix tile (a kinematic tree's diagonal block, row stride odd)
 constexpr int TB = 64;                  // largest tree (dofs) a team build takes
 constexpr int TSTR = TB + 1;
-constexpr int TL_VEC = 0, TL_ROW = TL_VEC + 2*NVX, TL_TILE = TL_ROW + NVX;
-constexpr int TEAM_LDS_WORDS = TEAMED ? TL_TILE + TB*TSTR : 1;
+// (and the solver's vectors: one copy per env instead of one per lane in scratch)
+constexpr int TL_VEC = 0, TL_X = TL_VEC + 2*NVX, TL_Q = TL_X + NVX, TL_MA = TL_Q + NVX,
+              TL_MV = TL_MA + NVX, TL_FS = TL_MV + NVX, TL_FC = TL_FS + NVX,
+              TL_ROW = TL_FC + NVX, TL_TILE = TL_ROW + NVX, TL_GEOM = TL_TILE + TB*TSTR;
+// ... and the geom-pose mirror the narrowphase reads
+constexpr int TEAM_LDS_WORDS = TEAMED ? TL_GEOM + 12*(NGEOM > 0 ? NGEOM : 1) : 1;
 
 template <bool T> struct WsRowT { typedef GlbRow type; };
 template <> struct WsRowT<true> { typedef TeamRow type; };
@@ -1005,7 +1009,10 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* lo
   }
   return nbad;
 }
-// x <- F^-T F^-1 x inside the envelope `lo` (x replicated before and after)
+// The vectors of team_solve / team_symv are SHARED (one copy in the team's LDS):
+// a lane reads any entry, entry k is written by lane k mod TEAM (or by lane 0
+// where every lane holds the value), with a phase boundary before it is read.
+// x <- F^-T F^-1 x inside the envelope `lo`
 template <class Mat>
 DEV void team_solve(real* x, const Mat& F, const int* lo) {
   const int tl = tlane();
@@ -1028,11 +1035,14 @@ DEV void team_solve(real* x, const Mat& F, const int* lo) {
       if (i < NV) {
         real p = kk[u] < i ? a[u]*x[kk[u]] : R(0);
         for (int k = kk[u] + TEAM; k < i; k += TEAM) p += F.get(tri(i, k))*x[k];
-        x[i] = (x[i] - tsum(p))*dg[u];
+        const real xi = (x[i] - tsum(p))*dg[u];
+        tsync();                 // (the shim's lanes: everyone has read x[i])
+        if (tl == 0) x[i] = xi;
+        tsync();
       }
     }
   }
-  // backward: lane k mod TEAM carries entry k; row i hands its value to the team
+  // backward: row i takes its final value and is subtracted from the earlier entries
   for (int i1 = NV - 1; i1 >= 0; i1 -= 8) {
     real a[8], dg[8];
     int kk[8];
@@ -1050,20 +1060,22 @@ DEV void team_solve(real* x, const Mat& F, const int* lo) {
     for (int u = 0; u < 8; u++) {
       const int i = i1 - u;
       if (i >= 0) {
-        const real xi = tget(x[i], i & (TEAM - 1))*dg[u];
-        x[i] = xi;
+        const real xi = x[i]*dg[u];
+        tsync();
+        if (tl == 0) x[i] = xi;
         if (kk[u] < i) x[kk[u]] -= a[u]*xi;
         for (int k = kk[u] + TEAM; k < i; k += TEAM) x[k] -= F.get(tri(i, k))*xi;
+        tsync();
       }
     }
   }
 }
-// y = A x (A symmetric, lower part stored inside the envelope `lo`)
+// y = A x (A symmetric, lower part stored inside the envelope `lo`); x, y shared
 template <class Mat>
 DEV void team_symv(const Work& W, real* y, const Mat& A, const real* x, const int* lo) {
   const int tl = tlane();
-  real* buf = W.lds + TL_VEC;
-  for (int k = tl; k < NV; k += TEAM) buf[k] = 0;      // column sums of the owned entries
+  real* buf = W.lds + TL_VEC;                            // what the rows below add to entry k
+  for (int k = tl; k < NV; k += TEAM) buf[k] = 0;
   for (int i0 = 0; i0 < NV; i0 += 8) {
     real a[8], dg[8];
     int kk[8];
@@ -1089,13 +1101,38 @@ DEV void team_symv(const Work& W, real* y, const Mat& A, const real* x, const in
           p += aik*x[k];
           buf[k] += aik*xi;
         }
-        y[i] = tsum(p) + dg[u]*xi;
+        const real yi = tsum(p) + dg[u]*xi;
+        if (tl == 0) y[i] = yi;
       }
     }
   }
   tsync();
-  for (int k = 0; k < NV; k++) y[k] += buf[k];
+  for (int k = tl; k < NV; k += TEAM) y[k] += buf[k];
   tsync();
+}
+// shared <- every lane's copy (all equal) / every lane's copy <- shared
+DEV void team_put(real* shared, const real* mine) {
+  for (int k = tlane(); k < NV; k += TEAM) shared[k] = mine[k];
+  tsync();
+}
+DEV void team_take(real* mine, const real* shared) {
+  for (int k = 0; k < NV; k++) mine[k] = shared[k];
+  tsync();
+}
+DEV void tatomic_add(real* p, real v) {       // LDS; the order of the additions is not fixed
+#if defined(DMC_TEAM) && !defined(DMC_HOST_SHIM)
+  atomicAdd(p, v);
+#elif defined(DMC_TEAM)
+  typedef typename pick_<sizeof(real) == 8, unsigned long long, unsigned>::type bits;
+  bits* q = reinterpret_cast<bits*>(p);
+  bits cur = __atomic_load_n(q, __ATOMIC_RELAXED), nxt;
+  do {
+    real c; memcpy(&c, &cur, sizeof c);
+    c += v; memcpy(&nxt, &c, sizeof c);
+  } while (!__atomic_compare_exchange_n(q, &cur, nxt, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+#else
+  *p += v;
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1472,7 +1509,12 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
   }
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qacc_smooth[i] = E.qfrc_smooth[i];
-  if (TEAMED) team_solve(E.qacc_smooth, Mats::L(E, W), E.mlo);
+  if (TEAMED) {
+    real* x = W.lds + TL_X;
+    team_put(x, E.qacc_smooth);
+    team_solve(x, Mats::L(E, W), E.mlo);
+    team_take(E.qacc_smooth, x);
+  }
   else if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
   else chol_solve(E.qacc_smooth, Mats::L(E, W));
 }
@@ -1707,7 +1749,7 @@ template <> struct PoseSrc<true> {
 template <class Poses>
 DEV void geom_poses(const Env& E, const Poses& G) {
   DMC_UNROLL
-  for (int g = 0; g < NGEOM; g++) {
+  for (int g = TEAMED ? tlane() : 0; g < NGEOM; g += TEAM) {     // (team mode: a geom per lane)
     const int b = geom_bodyid[g];
     real gp[3] = {R(geom_pos[3*g]), R(geom_pos[3*g + 1]), R(geom_pos[3*g + 2])};
     real gq[4] = {R(geom_quat[4*g]), R(geom_quat[4*g + 1]), R(geom_quat[4*g + 2]),
@@ -2183,8 +2225,8 @@ DEV real tmaxr(real x) {
 }
 DEV void detect_contacts_team(Env& E, const Work& W) {
   const int tl = tlane();
-  const auto G = PoseSrc<MAT_IN_WS>::make(W, nullptr);
-  geom_poses(E, G);              // (every lane writes the same mirror)
+  const ArrPoses G = {W.lds + TL_GEOM};      // the mirror lives in the team's LDS
+  geom_poses(E, G);
   tsync();
   constexpr int NTREEX = NTREE > 0 ? NTREE : 1;
   real tcen[NTREEX*3], trad[NTREEX];
@@ -2422,6 +2464,101 @@ DEV void rows_of_contact(Env& E, const Work& W, const Rec& rec) {
   if (PLANAR_MERGE && merged) rec.set(10, (real)(p + MERGE_STRIDE*merged));
 }
 
+// Team mode: the rows of one contact, built over the span of the two bodies'
+// dof chains only (a foot on the ground: the <= 26 dofs between the foot and its
+// walker's root, not the 254 of the pitch).  Same rows as rows_of_contact().
+template <class Row>
+DEV void write_row_span(const Row& rec, const Env& E, const real* row, int lo, int hi,
+                        real pm, real K, real B, real imp, real Rrow) {
+  int first = -1, last = -1;
+  real vel = 0;
+  for (int j = lo; j <= hi; j++) {
+    const real v = row[j];
+    rec.set(j, v);
+    if (v != 0) { if (first < 0) first = j; last = j; vel += v*E.qvel[j]; }
+  }
+  if (first < 0) first = last = lo;
+  rec.set(ROW_LO, (real)first); rec.set(ROW_HI, (real)last);
+  rec.set(ROW_AREF, -B*vel - K*imp*pm);
+  rec.set(ROW_D, R(1)/(Rrow < DMC_MINVAL ? DMC_MINVAL : Rrow));
+}
+DEV bool push_row_span(Env& E, const Work& W, const real* row, int lo, int hi, real pm,
+                       real K, real B, real imp, real Rrow) {
+  if (E.nefc >= NEFC_MAX) { E.warn |= WARN_CNSTRFULL; return false; }
+  write_row_span(W.grow(E.nefc++), E, row, lo, hi, pm, K, B, imp, Rrow);
+  return true;
+}
+template <class Rec>
+DEV void rows_of_contact_team(Env& E, const Work& W, const Rec& rec) {
+  const int p = (int)rec.get(10);
+  const real dist = rec.get(9);
+  const real includemargin = pair_includemargin[p];
+  if (dist >= includemargin) return;
+  real pos[3], fin[6], f[9];
+  for (int k = 0; k < 3; k++) { pos[k] = rec.get(k); fin[k] = rec.get(3 + k); fin[3 + k] = rec.get(6 + k); }
+  make_frame(fin, f);
+  const int b1 = pair_b1[p], b2 = pair_b2[p];
+  const int dim = pair_dim[p];
+  const int n1 = body_chain_len[b1], n2 = body_chain_len[b2];
+  int lo = NV, hi = -1;
+  for (int c = 0; c < n1; c++) { const int i = body_chain[b1*MAXCHAIN + c]; lo = i < lo ? i : lo; hi = i > hi ? i : hi; }
+  for (int c = 0; c < n2; c++) { const int i = body_chain[b2*MAXCHAIN + c]; lo = i < lo ? i : lo; hi = i > hi ? i : hi; }
+  if (hi < 0) lo = hi = 0;
+  real off1[3], off2[3];
+  for (int k = 0; k < 3; k++) {
+    off1[k] = n1 ? pos[k] - E.subtree_com[3*body_rootid[b1] + k] : R(0);
+    off2[k] = n2 ? pos[k] - E.subtree_com[3*body_rootid[b2] + k] : R(0);
+  }
+  const real pm = dist - includemargin;
+  const real imp = impedance(pair_solimp + 5*p, pm);
+  const real K = pair_K[p], B = pair_B[p];
+  real jb[3][NVX], jt[NVX], row[NVX];
+  for (int d = 0; d < 3; d++) {
+    const real* dir = f + 3*d;
+    real w1[3], w2[3];
+    cross3(w1, off1, dir);
+    cross3(w2, off2, dir);
+    for (int j = lo; j <= hi; j++) jb[d][j] = 0;
+    for (int c = 0; c < n2; c++) {
+      const int i = body_chain[b2*MAXCHAIN + c];
+      const real* cd = E.cdof + 6*i;
+      jb[d][i] += dot3(dir, cd + 3) + dot3(w2, cd);
+    }
+    for (int c = 0; c < n1; c++) {
+      const int i = body_chain[b1*MAXCHAIN + c];
+      const real* cd = E.cdof + 6*i;
+      jb[d][i] -= dot3(dir, cd + 3) + dot3(w1, cd);
+    }
+  }
+  if (dim == 1) {
+    const real Rr = (1 - imp)*pair_diag[6*p]/imp;
+    push_row_span(E, W, jb[0], lo, hi, pm, K, B, imp, Rr);
+    return;
+  }
+  const real mu0 = pair_friction[5*p];
+  real R0 = (1 - imp)*pair_diag[6*p + 1]/imp;
+  if (R0 < DMC_MINVAL) R0 = DMC_MINVAL;
+  const real Rpy = 2*mu0*mu0*R0;
+  for (int k = 1; k < 3; k++) {
+    const real mu = pair_friction[5*p + k - 1];
+    for (int j = lo; j <= hi; j++) row[j] = jb[0][j] + mu*jb[k][j];
+    push_row_span(E, W, row, lo, hi, pm, K, B, imp, Rpy);
+    for (int j = lo; j <= hi; j++) row[j] = jb[0][j] - mu*jb[k][j];
+    push_row_span(E, W, row, lo, hi, pm, K, B, imp, Rpy);
+  }
+  for (int k = 3; k < 6; k++) {      // torsional / rolling edges
+    if (k >= dim) continue;
+    const real* dir = f + 3*(k - 3);
+    const real mu = pair_friction[5*p + k - 1];
+    for (int j = lo; j <= hi; j++) jt[j] = 0;
+    for (int c = 0; c < n2; c++) { const int i = body_chain[b2*MAXCHAIN + c]; jt[i] += dot3(dir, E.cdof + 6*i); }
+    for (int c = 0; c < n1; c++) { const int i = body_chain[b1*MAXCHAIN + c]; jt[i] -= dot3(dir, E.cdof + 6*i); }
+    for (int j = lo; j <= hi; j++) row[j] = jb[0][j] + mu*jt[j];
+    push_row_span(E, W, row, lo, hi, pm, K, B, imp, Rpy);
+    for (int j = lo; j <= hi; j++) row[j] = jb[0][j] - mu*jt[j];
+    push_row_span(E, W, row, lo, hi, pm, K, B, imp, Rpy);
+  }
+}
 static_assert(!(TEAMED && PLANAR_MERGE), "team mode: no merged pyramid rows");
 // rows a contact record will push (team mode: known before they are written)
 template <class Rec>
@@ -2441,7 +2578,7 @@ DEV void contact_rows(Env& E, const Work& W) {
       const int mine = k < E.ncon ? rows_of_contact_count(W.gcon(k)) : 0;
       int total;
       const int first = E.nefc, at = tscan(mine, total);
-      if (mine > 0) { E.nefc = first + at; rows_of_contact(E, W, W.gcon(k)); }
+      if (mine > 0) { E.nefc = first + at; rows_of_contact_team(E, W, W.gcon(k)); }
       E.warn = tor(E.warn);
       E.nefc = first + total < NEFC_MAX ? first + total : NEFC_MAX;
     }
@@ -2680,17 +2817,24 @@ DEV void solve_newton(Env& E, const Work& W, real tol, bool start_smooth) {
   E.iters = iter;
 }
 
-// Team-mode Newton solver: the algorithm of solve_newton() with the passes over
-// the rows run one row per lane, the Hessian kept and factored tile by tile
-// (team_factor) and the sums over rows and dofs taken as team sums.
+// Team-mode Newton solver: the algorithm of solve_newton() with the vectors in
+// the team's LDS (one copy per env), the passes over the rows run one row per
+// lane, the Hessian kept and factored tile by tile (team_factor) and the sums
+// over rows and dofs taken as team sums.
 DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
-  real Ma[NVX], Mv[NVX], grad[NVX], search[NVX], fc[NVX];
+  real* const q = W.lds + TL_Q;        // qacc
+  real* const Ma = W.lds + TL_MA;
+  real* const Mv = W.lds + TL_MV;
+  real* const fs = W.lds + TL_FS;      // qfrc_smooth
+  real* const fc = W.lds + TL_FC;      // qfrc_constraint
+  real* const search = W.lds + TL_X;
   const auto M = Mats::M(E, W);
   const auto H = Mats::local(nullptr, W, MAT_H);
   const auto F = Mats::L(E, W);
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
   const int tl = tlane();
+  for (int i = tl; i < NV; i += TEAM) { q[i] = E.qacc[i]; fs[i] = E.qfrc_smooth[i]; }
   // envelope of the Hessian: M's, widened by the rows whose dofs lie in two trees
   {
     for (int i = 0; i < NV; i++) E.hlo[i] = dof_treeroot[i];
@@ -2712,16 +2856,16 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
       }
       tsync();
       for (int i = 0; i < NV; i++) E.hlo[i] = hl[i];
-      tsync();
     }
-    env_last_rows(E.hhi, E.hlo);
+    tsync();
   }
-  team_symv(W, Ma, M, E.qacc, E.mlo);
+  team_symv(W, Ma, M, q, E.mlo);
   real improvement = 0, alpha_prev = 0;
   int iter = 0;
   for (;; iter++) {
     // pass A: one row per lane
-    for (int i = 0; i < NV; i++) fc[i] = 0;
+    for (int i = tl; i < NV; i += TEAM) fc[i] = 0;
+    tsync();
     bool changed = false;
     for (int r = tl; r < nefc; r += TEAM) {
       const auto rec = W.grow(r);
@@ -2744,41 +2888,43 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
         for (; j + 8 <= jhi + 1; j += 8) {
           real a[8];
           _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = rec.get(j + u);
-          _Pragma("unroll") for (int u = 0; u < 8; u++) fc[j + u] += a[u]*f;
+          _Pragma("unroll") for (int u = 0; u < 8; u++) if (a[u] != 0) tatomic_add(fc + j + u, a[u]*f);
         }
-        for (; j <= jhi; j++) fc[j] += rec.get(j)*f;
+        for (; j <= jhi; j++) { const real a = rec.get(j); if (a != 0) tatomic_add(fc + j, a*f); }
       }
       rec.set(ROW_FLIP, now != was ? (now ? D : -D) : R(0));
       changed |= now != was;
     }
     changed = tany(changed);
-    tsync();                      // ROW_FLIP / ROW_JAR are read by other lanes from here on
+    tsync();                      // fc, ROW_FLIP and ROW_JAR are read by other lanes from here on
     real gn = 0;
-    for (int i = 0; i < NV; i++) {
-      E.qfrc_constraint[i] = tsum(fc[i]);
-      grad[i] = Ma[i] - E.qfrc_smooth[i] - E.qfrc_constraint[i];
-      gn += grad[i]*grad[i];
+    for (int i = tl; i < NV; i += TEAM) {
+      const real g = Ma[i] - fs[i] - fc[i];
+      search[i] = -g;
+      gn += g*g;
     }
+    gn = tsum(gn);
     const bool converged = DMC_F32_RULES && iter > 0 && !changed &&
                            fabs(alpha_prev - 1) < R(1e-3);
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
-    for (int i = 0; i < NV; i++) search[i] = -grad[i];
+    tsync();
     if (iter == 0) team_factor(W, F, M, E.hlo, R(0), true, true, nefc, H);
     else team_factor(W, F, H, E.hlo, R(0), true, false, nefc, H);
     team_solve(search, F, E.hlo);
     real sn = 0;
-    for (int i = 0; i < NV; i++) sn += search[i]*search[i];
-    sn = sqrt(sn);
+    for (int i = tl; i < NV; i += TEAM) sn += search[i]*search[i];
+    sn = sqrt(tsum(sn));
     alpha_prev = 0;
     if (sn < DMC_MINVAL) break;
     const real gtol = tol*R(0.01)*sn/scale;
     team_symv(W, Mv, M, search, E.mlo);
     real q1 = 0, q2 = 0;
-    for (int i = 0; i < NV; i++) {
-      q1 += search[i]*(Ma[i] - E.qfrc_smooth[i]);
+    for (int i = tl; i < NV; i += TEAM) {
+      q1 += search[i]*(Ma[i] - fs[i]);
       q2 += R(0.5)*search[i]*Mv[i];
     }
+    q1 = tsum(q1); q2 = tsum(q2);
     // pass B: Jv and the line-search sums at alpha = 0 (and, fp32, at alpha = 1)
     LsPoint p0, p, best;
     {
@@ -2852,12 +2998,15 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     const real alpha = best.alpha;
     if (alpha == 0) break;
     improvement = -best.dcost;
-    for (int i = 0; i < NV; i++) { E.qacc[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
+    for (int i = tl; i < NV; i += TEAM) { q[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
     alpha_prev = alpha;
+    tsync();
   }
+  tsync();
+  for (int i = 0; i < NV; i++) { E.qacc[i] = q[i]; E.qfrc_constraint[i] = fc[i]; }
+  tsync();
   E.iters = iter;
 }
-
 
 // ---------------------------------------------------------------------------
 // touch sensors (mjSENS_TOUCH in mj_sensorAcc): sum of the normal forces of the
@@ -3005,7 +3154,13 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
     const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
     real Ma[NVX], cw = 0, cs = 0;
     if (try_warm) {
-      if (TEAMED) team_symv(W, Ma, Mats::M(E, W), E.warm, E.mlo);
+      if (TEAMED) {
+        real* x = W.lds + TL_X;
+        real* y = W.lds + TL_MA;
+        team_put(x, E.warm);
+        team_symv(W, y, Mats::M(E, W), x, E.mlo);
+        team_take(Ma, y);
+      }
       else if (MAT_IN_WS) symv_env(Ma, Mats::M(E, W), E.warm, LoTree{});
       else symv(Ma, Mats::M(E, W), E.warm);
       DMC_UNROLL
@@ -3175,7 +3330,10 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
       if (TEAMED) {
         for (int i = 0; i < NV; i++) qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
         team_factor(W, A, M, E.mlo, h, false, false, 0, A);
-        team_solve(qacc, A, E.mlo);
+        real* x = W.lds + TL_X;
+        team_put(x, qacc);
+        team_solve(x, A, E.mlo);
+        team_take(qacc, x);
       } else {
       if (MAT_IN_WS) copy_env(A, M, LoTree{}, LoTree{});
       else {

@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 3, call 7: team build v2 (solver vectors / geom mirror in LDS, chain-based contact rows)
+O=gpurun_out/r03g; mkdir -p $O
+timeout -k 10 900 python -m pytest tests/test_soccer_model.py -m gpu -x -q -s -k "pitch and team" > $O/pitch_tests.log 2>&1; rc=$?
+echo "pytest rc=$rc"; grep -E "OBSERVED|passed|failed|Error|error" $O/pitch_tests.log | tail -20
+[ $rc -eq 0 ] || exit 1
+timeout -k 10 300 python tools/debug/pitch_profile.py loud --team > $O/pitch_profile_team_loud.txt 2>&1 && cat $O/pitch_profile_team_loud.txt &&
+timeout -k 10 300 python tools/debug/pitch_profile.py loud --team --f64 > $O/pitch_profile_team_loud_f64.txt 2>&1 && cat $O/pitch_profile_team_loud_f64.txt
