@@ -680,7 +680,9 @@ constexpr int TSTR = TB + 1;
 // (and the solver's vectors: one copy per env instead of one per lane in scratch)
 constexpr int TL_VEC = 0, TL_X = TL_VEC + 2*NVX, TL_Q = TL_X + NVX, TL_MA = TL_Q + NVX,
               TL_MV = TL_MA + NVX, TL_FS = TL_MV + NVX, TL_FC = TL_FS + NVX,
-              TL_ROW = TL_FC + NVX, TL_TILE = TL_ROW + NVX, TL_GEOM = TL_TILE + TB*TSTR;
+              TL_ROW = TL_FC + NVX, TL_TILE = TL_ROW + (NVX > 4*TB ? NVX : 4*TB),
+              TL_HLO = TL_TILE + TB*TSTR, TL_FLIPS = TL_HLO + NVX,
+              TL_GEOM = TL_FLIPS + 4*256;
 // ... and the geom-pose mirror the narrowphase reads
 constexpr int TEAM_LDS_WORDS = TEAMED ? TL_GEOM + 12*(NGEOM > 0 ? NGEOM : 1) : 1;
 
@@ -755,12 +757,17 @@ typedef MatsT<MAT_IN_WS> Mats;
 // ===========================================================================
 // Team algebra (team mode, big scenes).  Packed matrices live in the env's
 // workspace block with unit stride; a kinematic tree's diagonal block (<= TB
-// dofs) is worked on as a tile in the team's LDS.  Private vectors (x, y) are
-// replicated: every lane ends every function with the same values.
+// dofs) is worked on as a tile in the team's LDS.  Vectors are SHARED (one
+// copy in the team's LDS): a lane reads any entry, entry k is written by lane
+// k mod TEAM (or by lane 0 where every lane holds the value), with a phase
+// boundary before it is read.  An envelope is `hlo` (LDS ints: first column of
+// every row) or, hlo == nullptr, the kinematic trees' (dof_treeroot); bit t of
+// `coupled`: tree t has rows that start left of it (a contact between two trees).
 // ===========================================================================
-constexpr int KPL = (TB + TEAM - 1)/TEAM;       // tile columns per lane
+constexpr int KPL = (TB + TEAM - 1)/TEAM;       // tile columns (or rows) per lane
 static_assert(!TEAMED || MAT_IN_WS, "team mode is for scenes whose matrices live in the workspace");
 static_assert(!TEAMED || MAXTREEDOF <= TB, "team mode: a kinematic tree has at most TB dofs");
+static_assert(!TEAMED || NDTREE <= 32, "team mode: one bit per tree");
 
 #if defined(DMC_TEAM) && !defined(DMC_HOST_SHIM)
 DEV unsigned long long tballot(bool b) {
@@ -783,18 +790,34 @@ DEV void tatomic_min(int* p, int v) {
 DEV unsigned long long tballot(bool b) { return b ? 1ull : 0ull; }
 DEV void tatomic_min(int* p, int v) { if (v < *p) *p = v; }
 #endif
+DEV void tatomic_add(real* p, real v) {       // LDS; the order of the additions is not fixed
+#if defined(DMC_TEAM) && !defined(DMC_HOST_SHIM)
+  atomicAdd(p, v);
+#elif defined(DMC_TEAM)
+  typedef typename pick_<sizeof(real) == 8, unsigned long long, unsigned>::type bits;
+  bits* q = reinterpret_cast<bits*>(p);
+  bits cur = __atomic_load_n(q, __ATOMIC_RELAXED), nxt;
+  do {
+    real c; memcpy(&c, &cur, sizeof c);
+    c += v; memcpy(&nxt, &c, sizeof c);
+  } while (!__atomic_compare_exchange_n(q, &cur, nxt, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+#else
+  *p += v;
+#endif
+}
 DEV int tfirst_bit(unsigned long long m) { return __builtin_ctzll(m); }
+DEV int tpopc(unsigned long long m) { return __builtin_popcountll(m); }
 // first k >= lo that lane `tl` owns (k = tl mod TEAM)
 DEV int towned_from(int lo, int tl) { return lo + ((tl - lo) & (TEAM - 1)); }
 
-// tile <- A[s .. s+n-1][s .. row]; sixteen rows in flight
+// tile <- A[s .. s+n-1][s .. row]; 32 rows in flight
 template <class Mat>
 DEV void tile_load(real* T, const Mat& A, int s, int n) {
   const int tl = tlane();
-  for (int i0 = 0; i0 < n; i0 += 16) {
-    real a[16][KPL];
+  for (int i0 = 0; i0 < n; i0 += 32) {
+    real a[32][KPL];
     _Pragma("unroll")
-    for (int u = 0; u < 16; u++) {
+    for (int u = 0; u < 32; u++) {
       const int ii = i0 + u;
       _Pragma("unroll")
       for (int m = 0; m < KPL; m++) {
@@ -803,7 +826,7 @@ DEV void tile_load(real* T, const Mat& A, int s, int n) {
       }
     }
     _Pragma("unroll")
-    for (int u = 0; u < 16; u++) {
+    for (int u = 0; u < 32; u++) {
       const int ii = i0 + u;
       _Pragma("unroll")
       for (int m = 0; m < KPL; m++) {
@@ -821,7 +844,9 @@ DEV void tile_store(const Mat& A, const real* T, int s, int n) {
     for (int k = tl; k <= ii; k += TEAM) A.set(tri(s + ii, s + k), T[ii*TSTR + k]);
   tsync();
 }
-// in place T = L L^T (lower part), the diagonal keeps the inverse pivots
+// in place T = L L^T (lower part), the diagonal keeps the inverse pivots.  One
+// row per lane; the update of a row runs eight columns at a time so that the LDS
+// round trips of a block overlap.
 DEV int tile_factor(real* T, int n) {
   const int tl = tlane();
   int nbad = 0;
@@ -834,8 +859,15 @@ DEV int tile_factor(real* T, int n) {
     if (tl == 0) T[j*TSTR + j] = inv;
     tsync();
     for (int ii = j + 1 + tl; ii < n; ii += TEAM) {
-      const real lij = T[ii*TSTR + j];
-      for (int k = j + 1; k <= ii; k++) T[ii*TSTR + k] -= lij*T[k*TSTR + j];
+      real* row = T + ii*TSTR;
+      const real lij = row[j];
+      int k = j + 1;
+      for (; k + 8 <= ii + 1; k += 8) {
+        real c[8], r[8];
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { c[u] = T[(k + u)*TSTR + j]; r[u] = row[k + u]; }
+        _Pragma("unroll") for (int u = 0; u < 8; u++) row[k + u] = r[u] - lij*c[u];
+      }
+      for (; k <= ii; k++) row[k] -= lij*T[k*TSTR + j];
     }
     tsync();
   }
@@ -854,16 +886,16 @@ DEV real env_dot2(const Mat& A, int bi, int bj, int k0, int k1) {
   for (; k < k1; k++) t += A.get(bi + k)*A.get(bj + k);
   return t;
 }
-// rows of the tree [s, e] whose envelope starts left of it (a contact couples the
-// tree to an earlier one): their entries left of the tile, one row per lane
+// rows of the tree [s, e] whose envelope starts left of it: their entries left of
+// the tile, one row per lane
 template <class Mat>
-DEV void team_coupled_left(const Mat& F, const Mat& H, const int* lo, int s, int e) {
+DEV void team_coupled_left(const Mat& F, const Mat& H, const int* hlo, int s, int e) {
   for (int i = s + tlane(); i <= e; i += TEAM) {
-    const int li = lo[i];
+    const int li = hlo[i];
     if (li >= s) continue;
     const int bi = tri(i, 0);
     for (int j = li; j < s; j++) {
-      const int lj = lo[j], bj = tri(j, 0);
+      const int lj = hlo[j], bj = tri(j, 0);
       const real t = H.get(bi + j) - env_dot2(F, bi, bj, li > lj ? li : lj, j);
       F.set(bi + j, t*F.get(bj + j));
     }
@@ -872,21 +904,85 @@ DEV void team_coupled_left(const Mat& F, const Mat& H, const int* lo, int s, int
 }
 // ... and what they take out of the tile
 template <class Mat>
-DEV void team_coupled_tile(real* T, const Mat& F, const int* lo, int s, int e) {
+DEV void team_coupled_tile(real* T, const Mat& F, const int* hlo, int s, int e) {
   for (int i = s + tlane(); i <= e; i += TEAM) {
-    const int li = lo[i];
+    const int li = hlo[i];
     if (li >= s) continue;
     for (int k = s; k <= i; k++) {
-      const int lk = lo[k];
+      const int lk = hlo[k];
       if (lk >= s) continue;
       T[(i - s)*TSTR + (k - s)] -= env_dot2(F, tri(i, 0), tri(k, 0), li > lk ? li : lk, s);
     }
   }
   tsync();
 }
-// pending changes of the Hessian (ROW_FLIP = +-D) of the rows that touch the
-// tile [s, e], applied to the tile in LDS; returns whether there were any
-DEV bool team_tile_flips(real* T, const Work& W, int nefc, int s, int e) {
+// One pending change of the Hessian: row `r` (dofs lo..hi) enters or leaves with
+// weight w = +-D; a one-dof row (joint limit) carries w = +-D J^2 and is one
+// diagonal entry.  Pass A of the solver lists them in LDS (in row order).
+constexpr int NFLIP = 256;                  // beyond it: the rows are scanned (ROW_FLIP)
+static_assert(TL_GEOM - TL_FLIPS == 4*NFLIP, "team LDS layout");
+struct FlipList { real* p; int n; };        // n < 0: not listed
+DEV void flip_apply_row(real* T, const real* seg, real w, int c0, int c1, int s) {
+  const int tl = tlane();
+  for (int j = c0; j <= c1; j++) {
+    const real vj = seg[j - s];
+    if (vj == 0) continue;
+    const real sj = w*vj;
+    for (int k = c0 + tl; k <= j; k += TEAM) {
+      const real vk = seg[k - s];
+      if (vk != 0) T[(j - s)*TSTR + (k - s)] += sj*vk;
+    }
+  }
+}
+// the listed changes that touch the tile [s, e]; four row segments in flight
+DEV bool team_tile_flips_listed(real* T, const Work& W, const FlipList& L, int s, int e) {
+  const int tl = tlane();
+  real* seg = W.lds + TL_ROW;
+  bool any = false;
+  int f = 0;
+  while (f < L.n) {
+    int ids[4], c0s[4], c1s[4], cnt = 0;
+    real ws[4];
+    for (; f < L.n && cnt < 4; f++) {
+      const real* q = L.p + 4*f;
+      const int lo = (int)q[1], hi = (int)q[2];
+      if (hi < s || lo > e) continue;
+      any = true;
+      if (lo == hi) {
+        if (tl == 0) T[(lo - s)*TSTR + (lo - s)] += q[3];
+        continue;
+      }
+      ids[cnt] = (int)q[0]; ws[cnt] = q[3];
+      c0s[cnt] = lo > s ? lo : s; c1s[cnt] = hi < e ? hi : e;
+      cnt++;
+    }
+    real v[4][KPL];
+    _Pragma("unroll")
+    for (int u = 0; u < 4; u++)
+      _Pragma("unroll")
+      for (int m = 0; m < KPL; m++) {
+        const int k = s + tl + m*TEAM;
+        v[u][m] = (u < cnt && k >= c0s[u] && k <= c1s[u]) ? W.grow(ids[u]).get(k) : R(0);
+      }
+    tsync();                       // (the one-dof updates above; the previous group's reads of seg)
+    _Pragma("unroll")
+    for (int u = 0; u < 4; u++)
+      _Pragma("unroll")
+      for (int m = 0; m < KPL; m++) {
+        const int k = tl + m*TEAM;
+        if (u < cnt && k < TB) seg[u*TB + k] = v[u][m];
+      }
+    tsync();
+    for (int u = 0; u < cnt; u++) {
+      flip_apply_row(T, seg + u*TB, ws[u], c0s[u], c1s[u], s);
+      tsync();
+    }
+  }
+  tsync();
+  return any;
+}
+// the same from the rows' ROW_FLIP words (more changes than the list holds)
+DEV bool team_tile_flips_scanned(real* T, const Work& W, int nefc, int s, int e) {
   const int tl = tlane();
   real* seg = W.lds + TL_ROW;
   bool any = false;
@@ -905,7 +1001,7 @@ DEV bool team_tile_flips(real* T, const Work& W, int nefc, int s, int e) {
       const auto rec = W.grow(r0 + b);
       const real Ds = rec.get(ROW_FLIP);
       const int lo = (int)rec.get(ROW_LO), hi = (int)rec.get(ROW_HI);
-      if (lo == hi) {                          // a joint limit: one diagonal entry
+      if (lo == hi) {
         if (tl == 0) { const real v = rec.get(lo); T[(lo - s)*TSTR + (lo - s)] += Ds*v*v; }
         tsync();
         continue;
@@ -913,28 +1009,17 @@ DEV bool team_tile_flips(real* T, const Work& W, int nefc, int s, int e) {
       const int c0 = lo > s ? lo : s, c1 = hi < e ? hi : e;
       for (int k = c0 + tl; k <= c1; k += TEAM) seg[k - s] = rec.get(k);
       tsync();
-      for (int j = c0; j <= c1; j++) {
-        const real vj = seg[j - s];
-        if (vj == 0) continue;
-        const real sj = Ds*vj;
-        for (int k = c0 + tl; k <= j; k += TEAM) {
-          const real vk = seg[k - s];
-          if (vk != 0) T[(j - s)*TSTR + (k - s)] += sj*vk;
-        }
-      }
+      flip_apply_row(T, seg, Ds, c0, c1, s);
       tsync();
     }
   }
   return any;
 }
-// the same for the entries LEFT of the tiles: rows whose dofs lie in two trees.
-// `first`: the coupled rows' left parts start from zero (M has nothing there).
+// the changes LEFT of the tiles: rows whose dofs lie in two trees.  `first`: the
+// coupled rows' left parts start from zero (M has nothing there).
 template <class Mat>
 DEV void team_cross_flips(const Mat& H, const Work& W, int nefc, const int* hlo, bool first) {
   const int tl = tlane();
-  bool coupled = false;
-  for (int i = 0; i < NV; i++) coupled |= hlo[i] < dof_treeroot[i];
-  if (!coupled) return;
   if (first) {
     for (int i = 0; i < NV; i++) {
       const int s = dof_treeroot[i];
@@ -978,12 +1063,13 @@ DEV void team_cross_flips(const Mat& H, const Work& W, int nefc, const int* hlo,
 // changes]), tree by tree.  `flips`: the Newton Hessian -- the changed tiles
 // also go back to `H`, rows coupled to an earlier tree take their left parts from H.
 template <class Mat>
-DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* lo,
-                    real damping_h, bool flips, bool first, int nefc, const Mat& H) {
+DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hlo,
+                    unsigned coupled, real damping_h, bool flips, const FlipList& L,
+                    bool first, int nefc, const Mat& H) {
   real* T = W.lds + TL_TILE;
   const int tl = tlane();
   int nbad = 0;
-  if (flips) team_cross_flips(H, W, nefc, lo, first);
+  if (flips && coupled) team_cross_flips(H, W, nefc, hlo, first);
   for (int t = 0; t < NDTREE; t++) {
     const int s = dtree_lo[t], e = dtree_hi[t], n = e - s + 1;
     tile_load(T, src, s, n);
@@ -992,16 +1078,12 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* lo
       tsync();
     }
     if (flips) {
-      const bool changed = team_tile_flips(T, W, nefc, s, e);
+      const bool changed = L.n >= 0 ? team_tile_flips_listed(T, W, L, s, e)
+                                    : team_tile_flips_scanned(T, W, nefc, s, e);
       if (changed || first) tile_store(H, T, s, n);
-      bool coupled = false;
-      for (int i = s; i <= e; i++) coupled |= lo[i] < s;
-      if (coupled) {
-#if defined(DMC_HOST_SHIM) && defined(DMC_TEAM_TRACE)
-        if (tl == 0) fprintf(stderr, "coupled tree %d first %d\n", t, (int)first);
-#endif
-        team_coupled_left(dst, H, lo, s, e);
-        team_coupled_tile(T, dst, lo, s, e);
+      if ((coupled >> t) & 1u) {
+        team_coupled_left(dst, H, hlo, s, e);
+        team_coupled_tile(T, dst, hlo, s, e);
       }
     }
     nbad += tile_factor(T, n);
@@ -1009,106 +1091,87 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* lo
   }
   return nbad;
 }
-// The vectors of team_solve / team_symv are SHARED (one copy in the team's LDS):
-// a lane reads any entry, entry k is written by lane k mod TEAM (or by lane 0
-// where every lane holds the value), with a phase boundary before it is read.
-// x <- F^-T F^-1 x inside the envelope `lo`
+// x <- F^-T F^-1 x, tile by tile: the tree's block of the factor in LDS, column
+// substitutions with one row per lane
 template <class Mat>
-DEV void team_solve(real* x, const Mat& F, const int* lo) {
+DEV void team_solve(const Work& W, real* x, const Mat& F, const int* hlo, unsigned coupled) {
+  real* T = W.lds + TL_TILE;
   const int tl = tlane();
-  for (int i0 = 0; i0 < NV; i0 += 8) {
-    real a[8], dg[8];
-    int kk[8];
-    _Pragma("unroll")
-    for (int u = 0; u < 8; u++) {
-      const int i = i0 + u;
-      kk[u] = 0; a[u] = 0; dg[u] = 0;
-      if (i < NV) {
-        kk[u] = towned_from(lo[i], tl);
-        a[u] = kk[u] < i ? F.get(tri(i, kk[u])) : R(0);
-        dg[u] = F.get(tri(i, i));
+  for (int t = 0; t < NDTREE; t++) {
+    const int s = dtree_lo[t], e = dtree_hi[t], n = e - s + 1;
+    tile_load(T, F, s, n);
+    if ((coupled >> t) & 1u) {            // what the earlier trees contribute to the coupled rows
+      for (int i = s + tl; i <= e; i += TEAM) {
+        const int li = hlo[i];
+        if (li >= s) continue;
+        const int bi = tri(i, 0);
+        real acc = 0;
+        int k = li;
+        for (; k + 8 <= s; k += 8) {
+          real a[8];
+          _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = F.get(bi + k + u);
+          _Pragma("unroll") for (int u = 0; u < 8; u++) acc += a[u]*x[k + u];
+        }
+        for (; k < s; k++) acc += F.get(bi + k)*x[k];
+        x[i] -= acc;
       }
+      tsync();
     }
-    _Pragma("unroll")
-    for (int u = 0; u < 8; u++) {
-      const int i = i0 + u;
-      if (i < NV) {
-        real p = kk[u] < i ? a[u]*x[kk[u]] : R(0);
-        for (int k = kk[u] + TEAM; k < i; k += TEAM) p += F.get(tri(i, k))*x[k];
-        const real xi = (x[i] - tsum(p))*dg[u];
-        tsync();                 // (the shim's lanes: everyone has read x[i])
-        if (tl == 0) x[i] = xi;
-        tsync();
-      }
+    for (int j = 0; j < n; j++) {
+      const real xj = x[s + j]*T[j*TSTR + j];
+      tsync();
+      if (tl == 0) x[s + j] = xj;
+      for (int ii = j + 1 + tl; ii < n; ii += TEAM) x[s + ii] -= T[ii*TSTR + j]*xj;
+      tsync();
     }
   }
-  // backward: row i takes its final value and is subtracted from the earlier entries
-  for (int i1 = NV - 1; i1 >= 0; i1 -= 8) {
-    real a[8], dg[8];
-    int kk[8];
-    _Pragma("unroll")
-    for (int u = 0; u < 8; u++) {
-      const int i = i1 - u;
-      kk[u] = 0; a[u] = 0; dg[u] = 0;
-      if (i >= 0) {
-        kk[u] = towned_from(lo[i], tl);
-        a[u] = kk[u] < i ? F.get(tri(i, kk[u])) : R(0);
-        dg[u] = F.get(tri(i, i));
-      }
+  for (int t = NDTREE - 1; t >= 0; t--) {
+    const int s = dtree_lo[t], e = dtree_hi[t], n = e - s + 1;
+    tile_load(T, F, s, n);
+    for (int i = n - 1; i >= 0; i--) {
+      const real xi = x[s + i]*T[i*TSTR + i];
+      tsync();
+      if (tl == 0) x[s + i] = xi;
+      for (int k = tl; k < i; k += TEAM) x[s + k] -= T[i*TSTR + k]*xi;
+      tsync();
     }
-    _Pragma("unroll")
-    for (int u = 0; u < 8; u++) {
-      const int i = i1 - u;
-      if (i >= 0) {
-        const real xi = x[i]*dg[u];
-        tsync();
-        if (tl == 0) x[i] = xi;
-        if (kk[u] < i) x[kk[u]] -= a[u]*xi;
-        for (int k = kk[u] + TEAM; k < i; k += TEAM) x[k] -= F.get(tri(i, k))*xi;
-        tsync();
+    if ((coupled >> t) & 1u) {            // the coupled rows push their values into the earlier trees
+      for (int i = s; i <= e; i++) {
+        const int li = hlo[i];
+        if (li >= s) continue;
+        const real xi = x[i];
+        const int bi = tri(i, 0);
+        for (int k = towned_from(li, tl); k < s; k += TEAM) x[k] -= F.get(bi + k)*xi;
       }
+      tsync();
     }
   }
 }
-// y = A x (A symmetric, lower part stored inside the envelope `lo`); x, y shared
+// y = M x for a matrix with the trees' envelope (block diagonal), tile by tile
 template <class Mat>
-DEV void team_symv(const Work& W, real* y, const Mat& A, const real* x, const int* lo) {
+DEV void team_symv(const Work& W, real* y, const Mat& A, const real* x) {
+  real* T = W.lds + TL_TILE;
   const int tl = tlane();
-  real* buf = W.lds + TL_VEC;                            // what the rows below add to entry k
-  for (int k = tl; k < NV; k += TEAM) buf[k] = 0;
-  for (int i0 = 0; i0 < NV; i0 += 8) {
-    real a[8], dg[8];
-    int kk[8];
-    _Pragma("unroll")
-    for (int u = 0; u < 8; u++) {
-      const int i = i0 + u;
-      kk[u] = 0; a[u] = 0; dg[u] = 0;
-      if (i < NV) {
-        kk[u] = towned_from(lo[i], tl);
-        a[u] = kk[u] < i ? A.get(tri(i, kk[u])) : R(0);
-        dg[u] = A.get(tri(i, i));
-      }
-    }
-    _Pragma("unroll")
-    for (int u = 0; u < 8; u++) {
-      const int i = i0 + u;
-      if (i < NV) {
-        const real xi = x[i];
-        real p = 0;
-        if (kk[u] < i) { p = a[u]*x[kk[u]]; buf[kk[u]] += a[u]*xi; }
-        for (int k = kk[u] + TEAM; k < i; k += TEAM) {
-          const real aik = A.get(tri(i, k));
-          p += aik*x[k];
-          buf[k] += aik*xi;
+  for (int t = 0; t < NDTREE; t++) {
+    const int s = dtree_lo[t], n = dtree_hi[t] - s + 1;
+    tile_load(T, A, s, n);
+    for (int ii = tl; ii < n; ii += TEAM) {
+      real acc = 0;
+      int k = 0;
+      for (; k + 8 <= n; k += 8) {
+        real a[8], b[8];
+        _Pragma("unroll") for (int u = 0; u < 8; u++) {
+          const int kk = k + u;
+          a[u] = kk <= ii ? T[ii*TSTR + kk] : T[kk*TSTR + ii];
+          b[u] = x[s + kk];
         }
-        const real yi = tsum(p) + dg[u]*xi;
-        if (tl == 0) y[i] = yi;
+        _Pragma("unroll") for (int u = 0; u < 8; u++) acc += a[u]*b[u];
       }
+      for (; k < n; k++) acc += (k <= ii ? T[ii*TSTR + k] : T[k*TSTR + ii])*x[s + k];
+      y[s + ii] = acc;
     }
+    tsync();
   }
-  tsync();
-  for (int k = tl; k < NV; k += TEAM) y[k] += buf[k];
-  tsync();
 }
 // shared <- every lane's copy (all equal) / every lane's copy <- shared
 DEV void team_put(real* shared, const real* mine) {
@@ -1118,21 +1181,6 @@ DEV void team_put(real* shared, const real* mine) {
 DEV void team_take(real* mine, const real* shared) {
   for (int k = 0; k < NV; k++) mine[k] = shared[k];
   tsync();
-}
-DEV void tatomic_add(real* p, real v) {       // LDS; the order of the additions is not fixed
-#if defined(DMC_TEAM) && !defined(DMC_HOST_SHIM)
-  atomicAdd(p, v);
-#elif defined(DMC_TEAM)
-  typedef typename pick_<sizeof(real) == 8, unsigned long long, unsigned>::type bits;
-  bits* q = reinterpret_cast<bits*>(p);
-  bits cur = __atomic_load_n(q, __ATOMIC_RELAXED), nxt;
-  do {
-    real c; memcpy(&c, &cur, sizeof c);
-    c += v; memcpy(&nxt, &c, sizeof c);
-  } while (!__atomic_compare_exchange_n(q, &cur, nxt, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
-#else
-  *p += v;
-#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -1345,7 +1393,7 @@ DEV void crb_factor(Env& E, const Work& W) {
       }
     }
     tsync();
-    if (team_factor(W, L, M, E.mlo, R(0), false, false, 0, L)) E.warn |= WARN_INERTIA;
+    if (team_factor(W, L, M, nullptr, 0u, R(0), false, FlipList{nullptr, -1}, false, 0, L)) E.warn |= WARN_INERTIA;
     return;
   }
   if (MAT_IN_WS) {
@@ -1512,7 +1560,7 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
   if (TEAMED) {
     real* x = W.lds + TL_X;
     team_put(x, E.qacc_smooth);
-    team_solve(x, Mats::L(E, W), E.mlo);
+    team_solve(W, x, Mats::L(E, W), nullptr, 0u);
     team_take(E.qacc_smooth, x);
   }
   else if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
@@ -2836,30 +2884,37 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
   const int tl = tlane();
   for (int i = tl; i < NV; i += TEAM) { q[i] = E.qacc[i]; fs[i] = E.qfrc_smooth[i]; }
   // envelope of the Hessian: M's, widened by the rows whose dofs lie in two trees
+  // (LDS ints); bit t of `coupled`: tree t has rows that start left of it
+  int* const hlo = reinterpret_cast<int*>(W.lds + TL_HLO);
+  unsigned coupled = 0;
   {
-    for (int i = 0; i < NV; i++) E.hlo[i] = dof_treeroot[i];
     bool cross = false;
     for (int r = tl; r < nefc; r += TEAM) {
       const auto rec = W.grow(r);
       cross |= (int)rec.get(ROW_LO) < dof_treeroot[(int)rec.get(ROW_HI)];
     }
     if (tany(cross)) {
-      int* hl = reinterpret_cast<int*>(W.lds + TL_VEC);
-      for (int i = tl; i < NV; i += TEAM) hl[i] = dof_treeroot[i];
+      for (int i = tl; i < NV; i += TEAM) hlo[i] = dof_treeroot[i];
       tsync();
       for (int r = tl; r < nefc; r += TEAM) {
         const auto rec = W.grow(r);
         const int lo = (int)rec.get(ROW_LO), hi = (int)rec.get(ROW_HI);
         if (!(lo < dof_treeroot[hi])) continue;
         for (int j = lo + 1; j <= hi; j++)
-          if (rec.get(j) != 0) tatomic_min(hl + j, lo);
+          if (rec.get(j) != 0) tatomic_min(hlo + j, lo);
       }
       tsync();
-      for (int i = 0; i < NV; i++) E.hlo[i] = hl[i];
+      for (int t = 0; t < NDTREE; t++) {
+        bool c = false;
+        for (int i = dtree_lo[t] + tl; i <= dtree_hi[t]; i += TEAM) c |= hlo[i] < dtree_lo[t];
+        if (tany(c)) coupled |= 1u << t;
+      }
     }
     tsync();
   }
-  team_symv(W, Ma, M, q, E.mlo);
+  const int* const henv = coupled ? hlo : nullptr;
+  FlipList flips = {W.lds + TL_FLIPS, 0};
+  team_symv(W, Ma, M, q);
   real improvement = 0, alpha_prev = 0;
   int iter = 0;
   for (;; iter++) {
@@ -2867,7 +2922,13 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     for (int i = tl; i < NV; i += TEAM) fc[i] = 0;
     tsync();
     bool changed = false;
-    for (int r = tl; r < nefc; r += TEAM) {
+    flips.n = 0;
+    for (int r0 = 0; r0 < nefc; r0 += TEAM) {
+      const int r = r0 + tl;
+      bool flipped = false;
+      real fw = 0;
+      int flo = 0, fhi = 0;
+      if (r < nefc) {
       const auto rec = W.grow(r);
       real jar = rec.get(ROW_JAR);
       const real jv = rec.get(ROW_JV), D = rec.get(ROW_D);
@@ -2893,9 +2954,26 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
         for (; j <= jhi; j++) { const real a = rec.get(j); if (a != 0) tatomic_add(fc + j, a*f); }
       }
       rec.set(ROW_FLIP, now != was ? (now ? D : -D) : R(0));
-      changed |= now != was;
+      if (now != was) {
+        flipped = true;
+        flo = (int)rec.get(ROW_LO); fhi = (int)rec.get(ROW_HI);
+        fw = now ? D : -D;
+        if (flo == fhi) { const real v = rec.get(flo); fw *= v*v; }
+      }
+      }
+      // the changes of this round, listed in row order
+      const unsigned long long fm = tballot(flipped);
+      if (flipped) {
+        const int at = flips.n + tpopc(fm & ((1ull << tl) - 1));
+        if (at < NFLIP) {
+          real* e = flips.p + 4*at;
+          e[0] = (real)r; e[1] = (real)flo; e[2] = (real)fhi; e[3] = fw;
+        }
+      }
+      flips.n += tpopc(fm);
+      changed |= fm != 0;
     }
-    changed = tany(changed);
+    if (flips.n > NFLIP) flips.n = -1;          // too many to list: team_factor scans the rows
     tsync();                      // fc, ROW_FLIP and ROW_JAR are read by other lanes from here on
     real gn = 0;
     for (int i = tl; i < NV; i += TEAM) {
@@ -2909,16 +2987,16 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
     tsync();
-    if (iter == 0) team_factor(W, F, M, E.hlo, R(0), true, true, nefc, H);
-    else team_factor(W, F, H, E.hlo, R(0), true, false, nefc, H);
-    team_solve(search, F, E.hlo);
+    if (iter == 0) team_factor(W, F, M, henv, coupled, R(0), true, flips, true, nefc, H);
+    else team_factor(W, F, H, henv, coupled, R(0), true, flips, false, nefc, H);
+    team_solve(W, search, F, henv, coupled);
     real sn = 0;
     for (int i = tl; i < NV; i += TEAM) sn += search[i]*search[i];
     sn = sqrt(tsum(sn));
     alpha_prev = 0;
     if (sn < DMC_MINVAL) break;
     const real gtol = tol*R(0.01)*sn/scale;
-    team_symv(W, Mv, M, search, E.mlo);
+    team_symv(W, Mv, M, search);
     real q1 = 0, q2 = 0;
     for (int i = tl; i < NV; i += TEAM) {
       q1 += search[i]*(Ma[i] - fs[i]);
@@ -3158,7 +3236,7 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
         real* x = W.lds + TL_X;
         real* y = W.lds + TL_MA;
         team_put(x, E.warm);
-        team_symv(W, y, Mats::M(E, W), x, E.mlo);
+        team_symv(W, y, Mats::M(E, W), x);
         team_take(Ma, y);
       }
       else if (MAT_IN_WS) symv_env(Ma, Mats::M(E, W), E.warm, LoTree{});
@@ -3329,10 +3407,10 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
       const LaneMat A = Mats::local(Areg, W, MAT_A);
       if (TEAMED) {
         for (int i = 0; i < NV; i++) qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
-        team_factor(W, A, M, E.mlo, h, false, false, 0, A);
+        team_factor(W, A, M, nullptr, 0u, h, false, FlipList{nullptr, -1}, false, 0, A);
         real* x = W.lds + TL_X;
         team_put(x, qacc);
-        team_solve(x, A, E.mlo);
+        team_solve(W, x, A, nullptr, 0u);
         team_take(qacc, x);
       } else {
       if (MAT_IN_WS) copy_env(A, M, LoTree{}, LoTree{});
