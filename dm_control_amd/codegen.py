@@ -494,6 +494,22 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   tree_of_body = [-1 if int(r) == 0 else roots.index(int(r)) for r in m.body_rootid]
   tree_of_body[0] = -1
   ci('NTREE', len(roots) if m.nbody > 1 else 0)
+  # the trees as ranges of bodies, joints and dofs ([lo, hi), all consecutive): in
+  # team builds one lane per tree runs the tree-local recursions
+  tb_lo, tb_hi, tj_lo, tj_hi, td_lo, td_hi = [], [], [], [], [], []
+  for t in range(len(roots) if m.nbody > 1 else 0):
+    bodies = [b for b in range(1, m.nbody) if tree_of_body[b] == t]
+    assert bodies == list(range(bodies[0], bodies[-1] + 1)), 'tree bodies not consecutive'
+    tb_lo.append(bodies[0]); tb_hi.append(bodies[-1] + 1)
+    jn = [int(m.body_jntadr[b]) + k for b in bodies for k in range(int(m.body_jntnum[b]))]
+    dn = [int(m.body_dofadr[b]) + k for b in bodies for k in range(int(m.body_dofnum[b]))]
+    assert jn == list(range(jn[0], jn[-1] + 1)) if jn else True
+    assert dn == list(range(dn[0], dn[-1] + 1)) if dn else True
+    tj_lo.append(jn[0] if jn else 0); tj_hi.append(jn[-1] + 1 if jn else 0)
+    td_lo.append(dn[0] if dn else 0); td_hi.append(dn[-1] + 1 if dn else 0)
+  for name, vals in (('tree_body_lo', tb_lo), ('tree_body_hi', tb_hi), ('tree_jnt_lo', tj_lo),
+                     ('tree_jnt_hi', tj_hi), ('tree_dof_lo', td_lo), ('tree_dof_hi', td_hi)):
+    ti(name, vals or [0])
   ti('geom_tree', [tree_of_body[int(b)] for b in m.geom_bodyid] or [-1])
   ti('pair_tree1', [tree_of_body[int(m.geom_bodyid[p[0]])] for p in pairs] or [-1])
   ti('pair_tree2', [tree_of_body[int(m.geom_bodyid[p[1]])] for p in pairs] or [-1])

@@ -562,21 +562,50 @@ DEV void copy_env(const Mat& dst, const Mat& src, const Lo& lo, const SLo& slo) 
 // ---------------------------------------------------------------------------
 // per-lane working set of one environment
 // ---------------------------------------------------------------------------
+// Team mode: what one tree's recursions produce and another stage reads across
+// trees (body frames, dof axes, the force and acceleration vectors) is SHARED --
+// one copy in the team's LDS, the members below are pointers into it -- and the
+// recursions of a tree run on one lane (`rb0` ...: that tree's ranges), the four
+// walkers of a pitch on four lanes at once.
+#ifdef DMC_TEAM
+#define DMC_SHARED(name, n) real* name
+#define BODY_LO(E) ((E).rb0)
+#define BODY_LO0(E) ((E).rb0)
+#define BODY_HI(E) ((E).rb1)
+#define JNT_LO(E) ((E).rj0)
+#define JNT_HI(E) ((E).rj1)
+#define DOF_LO(E) ((E).rd0)
+#define DOF_HI(E) ((E).rd1)
+#else
+#define DMC_SHARED(name, n) real name[n]
+#define BODY_LO(E) 1
+#define BODY_LO0(E) 0
+#define BODY_HI(E) NBODY
+#define JNT_LO(E) 0
+#define JNT_HI(E) NJNT
+#define DOF_LO(E) 0
+#define DOF_HI(E) NV
+#endif
 struct Env {
   real qpos[NQ > 0 ? NQ : 1], qvel[NVX], ctrl[NUX], warm[NVX];
 #ifdef DMC_STATE_COMP
   real qpos_lo[NQ > 0 ? NQ : 1], qvel_lo[NVX];   // low words of the fp64 state
 #endif
-  real xpos[NBODY*3], xquat[NBODY*4], xmat[NBODY*9];
+#ifdef DMC_TEAM
+  int rb0, rb1, rj0, rj1, rd0, rd1;   // the bodies / joints / dofs this lane's recursions cover
+#endif
+  DMC_SHARED(xpos, NBODY*3); DMC_SHARED(xquat, NBODY*4); DMC_SHARED(xmat, NBODY*9);
   // (big scenes, MAT_IN_WS: the inertial frames are recomputed where com_pos
   // needs them instead of being kept -- the fp64 frame must stay below 128 KB)
   real xipos[NBODY*3], ximat[MAT_IN_WS ? 9 : NBODY*9];
   real xanchor[(NJNT > 0 ? NJNT : 1)*3], xaxis[(NJNT > 0 ? NJNT : 1)*3];
-  real subtree_com[NBODY*3];
+  DMC_SHARED(subtree_com, NBODY*3);
   real cinert[NBODY*10];
-  real cdof[NVX*6], cdof_dot[NVX*6], cvel[NBODY*6];
+  DMC_SHARED(cdof, NVX*6);
+  real cdof_dot[NVX*6], cvel[NBODY*6];
   real qM[MAT_REGS], qL[MAT_REGS];
-  real qfrc_smooth[NVX], qfrc_constraint[NVX], qacc_smooth[NVX], qacc[NVX];
+  DMC_SHARED(qfrc_smooth, NVX); DMC_SHARED(qfrc_constraint, NVX);
+  DMC_SHARED(qacc_smooth, NVX); DMC_SHARED(qacc, NVX);
   real subtree_linvel[NBODY*3];
   real touch[NTOUCH > 0 ? NTOUCH : 1];   // touch sensor readings (mj_sensorAcc)
   real taskdata[NTDX];                   // per-instance task parameters
@@ -677,14 +706,21 @@ enum { MAT_M = 0, MAT_L = 1, MAT_H = 2, MAT_A = 3 };
 // matrix tile (a kinematic tree's diagonal block, row stride odd)
 constexpr int TB = 64;                  // largest tree (dofs) a team build takes
 constexpr int TSTR = TB + 1;
-// (and the solver's vectors: one copy per env instead of one per lane in scratch)
+// (and the vectors of the dynamics: one copy per env instead of one per lane in scratch)
 constexpr int TL_VEC = 0, TL_X = TL_VEC + 2*NVX, TL_Q = TL_X + NVX, TL_MA = TL_Q + NVX,
-              TL_MV = TL_MA + NVX, TL_FS = TL_MV + NVX, TL_FC = TL_FS + NVX,
-              TL_ROW = TL_FC + NVX, TL_TILE = TL_ROW + (NVX > 4*TB ? NVX : 4*TB),
-              TL_HLO = TL_TILE + TB*TSTR, TL_FLIPS = TL_HLO + NVX,
-              TL_GEOM = TL_FLIPS + 4*256;
-// ... and the geom-pose mirror the narrowphase reads
-constexpr int TEAM_LDS_WORDS = TEAMED ? TL_GEOM + 12*(NGEOM > 0 ? NGEOM : 1) : 1;
+              TL_MV = TL_MA + NVX, TL_FS = TL_MV + NVX, TL_FC = TL_FS + NVX, TL_QAS = TL_FC + NVX,
+              TL_ROW = TL_QAS + NVX, TL_HLO = TL_ROW + (NVX > 4*TB ? NVX : 4*TB),
+              TL_PHASE = TL_HLO + NVX;
+// What follows is used in two phases of a step that do not overlap.  Phase 2
+// (linear algebra): the tile and the list of pending Hessian changes.
+constexpr int TL_TILE = TL_PHASE, TL_FLIPS = TL_TILE + TB*TSTR, TL_END2 = TL_FLIPS + 4*256;
+// Phase 1 (frames, forces, constraint rows): the geom-pose mirror the narrowphase
+// reads and the shared members of Env.
+constexpr int NGX_ = NGEOM > 0 ? NGEOM : 1;
+constexpr int TL_GEOM = TL_PHASE, TL_XPOS = TL_GEOM + 12*NGX_, TL_XQUAT = TL_XPOS + 3*NBODY,
+              TL_XMAT = TL_XQUAT + 4*NBODY, TL_SCOM = TL_XMAT + 9*NBODY,
+              TL_CDOF = TL_SCOM + 3*NBODY, TL_END1 = TL_CDOF + 6*NVX;
+constexpr int TEAM_LDS_WORDS = TEAMED ? (TL_END1 > TL_END2 ? TL_END1 : TL_END2) : 1;
 
 template <bool T> struct WsRowT { typedef GlbRow type; };
 template <> struct WsRowT<true> { typedef TeamRow type; };
@@ -920,7 +956,7 @@ DEV void team_coupled_tile(real* T, const Mat& F, const int* hlo, int s, int e) 
 // weight w = +-D; a one-dof row (joint limit) carries w = +-D J^2 and is one
 // diagonal entry.  Pass A of the solver lists them in LDS (in row order).
 constexpr int NFLIP = 256;                  // beyond it: the rows are scanned (ROW_FLIP)
-static_assert(TL_GEOM - TL_FLIPS == 4*NFLIP, "team LDS layout");
+static_assert(TL_END2 - TL_FLIPS == 4*NFLIP, "team LDS layout");
 struct FlipList { real* p; int n; };        // n < 0: not listed
 DEV void flip_apply_row(real* T, const real* seg, real w, int c0, int c1, int s) {
   const int tl = tlane();
@@ -1195,7 +1231,7 @@ DEV void kinematics(Env& E) {
   DMC_UNROLL
   for (int k = 0; k < 9; k++) E.ximat[k] = E.xmat[k];
   DMC_UNROLL
-  for (int i = 1; i < NBODY; i++) {
+  for (int i = BODY_LO(E); i < BODY_HI(E); i++) {
     real xpos[3], xquat[4];
     const int jadr = body_jntadr[i], jnum = body_jntnum[i];
     if (jnum == 1 && jnt_type[jadr < 0 ? 0 : jadr] == JNT_FREE) {
@@ -1274,17 +1310,19 @@ DEV void kinematics(Env& E) {
 
 DEV void com_pos(Env& E) {
   DMC_UNROLL
-  for (int i = 0; i < NBODY; i++)
+  for (int i = BODY_LO0(E); i < BODY_HI(E); i++)
     DMC_UNROLL
     for (int k = 0; k < 3; k++)
       E.subtree_com[3*i + k] = R(body_mass[i])*E.xipos[3*i + k];
   DMC_UNROLL
-  for (int i = NBODY - 1; i > 0; i--)
+  for (int i = BODY_HI(E) - 1; i >= BODY_LO(E); i--) {
+    if (TEAMED && body_parentid[i] == 0) continue;    // (the world's entry is shared and unused)
     DMC_UNROLL
     for (int k = 0; k < 3; k++)
       E.subtree_com[3*body_parentid[i] + k] += E.subtree_com[3*i + k];
+  }
   DMC_UNROLL
-  for (int i = 0; i < NBODY; i++) {
+  for (int i = BODY_LO0(E); i < BODY_HI(E); i++) {
     if (body_subtreemass[i] < 1e-15) {
       DMC_UNROLL
       for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] = E.xipos[3*i + k];
@@ -1297,7 +1335,7 @@ DEV void com_pos(Env& E) {
   DMC_UNROLL
   for (int k = 0; k < 10; k++) E.cinert[k] = 0;
   DMC_UNROLL
-  for (int i = 1; i < NBODY; i++) {
+  for (int i = BODY_LO(E); i < BODY_HI(E); i++) {
     const real* com = E.subtree_com + 3*body_rootid[i];
     real mat_[9];
     if (MAT_IN_WS) {     // same two operations as in kinematics(), on the stored xquat
@@ -1331,7 +1369,7 @@ DEV void com_pos(Env& E) {
     res[9] = mass;
   }
   DMC_UNROLL
-  for (int j = 0; j < NJNT; j++) {
+  for (int j = JNT_LO(E); j < JNT_HI(E); j++) {
     const int b = jnt_bodyid[j], da = jnt_dofadr[j];
     const real* com = E.subtree_com + 3*body_rootid[b];
     real off[3];
@@ -1364,6 +1402,27 @@ DEV void com_pos(Env& E) {
   }
 }
 
+// team mode: composite inertias and the rows of M of this lane's tree (the rows
+// were cleared by the team beforehand; forward_team() factors M afterwards)
+DEV void crb_tree(Env& E, const Work& W) {
+  const auto M = Mats::M(E, W);
+  real crb[NBODY*10];
+  for (int i = BODY_LO(E); i < BODY_HI(E); i++)
+    for (int k = 0; k < 10; k++) crb[10*i + k] = E.cinert[10*i + k];
+  for (int i = BODY_HI(E) - 1; i >= BODY_LO(E); i--)
+    if (body_parentid[i] > 0)
+      for (int k = 0; k < 10; k++) crb[10*body_parentid[i] + k] += crb[10*i + k];
+  for (int i = DOF_LO(E); i < DOF_HI(E); i++) {
+    real buf[6];
+    mul_inert_vec(buf, crb + 10*dof_bodyid[i], E.cdof + 6*i);
+    M.set(tri(i, i), dot6(E.cdof + 6*i, buf) + R(dof_armature[i]));
+    for (int a = 0; a < dof_anc_len[i]; a++) {
+      const int j = dof_anc[i*MAXCHAIN + a];
+      M.set(tri(i, j), dot6(E.cdof + 6*j, buf));
+    }
+  }
+}
+
 // composite rigid body algorithm -> packed M, then M = L L^T
 DEV void crb_factor(Env& E, const Work& W) {
   const auto M = Mats::M(E, W);
@@ -1376,26 +1435,6 @@ DEV void crb_factor(Env& E, const Work& W) {
     if (body_parentid[i] > 0)
       DMC_UNROLL
       for (int k = 0; k < 10; k++) crb[10*body_parentid[i] + k] += crb[10*i + k];
-  if (TEAMED) {
-    // rows of M inside the envelope: cleared by the team (lanes along a row), then
-    // one dof per lane writes its diagonal and ancestor entries
-    const int tl = tlane();
-    for (int i = 0; i < NV; i++)
-      for (int j = dof_treeroot[i] + tl; j <= i; j += TEAM) M.set(tri(i, j), 0);
-    tsync();
-    for (int i = tl; i < NV; i += TEAM) {
-      real buf[6];
-      mul_inert_vec(buf, crb + 10*dof_bodyid[i], E.cdof + 6*i);
-      M.set(tri(i, i), dot6(E.cdof + 6*i, buf) + R(dof_armature[i]));
-      for (int a = 0; a < dof_anc_len[i]; a++) {
-        const int j = dof_anc[i*MAXCHAIN + a];
-        M.set(tri(i, j), dot6(E.cdof + 6*j, buf));
-      }
-    }
-    tsync();
-    if (team_factor(W, L, M, nullptr, 0u, R(0), false, FlipList{nullptr, -1}, false, 0, L)) E.warn |= WARN_INERTIA;
-    return;
-  }
   if (MAT_IN_WS) {
     for (int i = 0; i < NV; i++)
       for (int j = dof_treeroot[i]; j <= i; j++) M.set(tri(i, j), 0);
@@ -1432,7 +1471,7 @@ DEV void com_vel(Env& E) {
   DMC_UNROLL
   for (int k = 0; k < 6; k++) E.cvel[k] = 0;
   DMC_UNROLL
-  for (int i = 1; i < NBODY; i++) {
+  for (int i = BODY_LO(E); i < BODY_HI(E); i++) {
     real cvel[6];
     DMC_UNROLL
     for (int k = 0; k < 6; k++) cvel[k] = E.cvel[6*body_parentid[i] + k];
@@ -1487,7 +1526,7 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
     DMC_UNROLL
     for (int k = 0; k < 3; k++) cacc[3 + k] = -R(gravity[k]);
   DMC_UNROLL
-  for (int i = 1; i < NBODY; i++) {
+  for (int i = BODY_LO(E); i < BODY_HI(E); i++) {
     real tmp[6], tmp1[6];
     const int da = body_dofadr[i];
     DMC_UNROLL
@@ -1504,16 +1543,16 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
     for (int k = 0; k < 6; k++) cfrc[6*i + k] += tmp1[k];
   }
   DMC_UNROLL
-  for (int i = NBODY - 1; i > 0; i--)
+  for (int i = BODY_HI(E) - 1; i >= BODY_LO(E); i--)
     if (body_parentid[i] > 0)
       DMC_UNROLL
       for (int k = 0; k < 6; k++) cfrc[6*body_parentid[i] + k] += cfrc[6*i + k];
   DMC_UNROLL
-  for (int i = 0; i < NV; i++)
+  for (int i = DOF_LO(E); i < DOF_HI(E); i++)
     E.qfrc_smooth[i] = -dot6(E.cdof + 6*i, cfrc + 6*dof_bodyid[i]);
   if (!(DISABLEFLAGS & DSBL_PASSIVE)) {
     DMC_UNROLL
-    for (int j = 0; j < NJNT; j++)
+    for (int j = JNT_LO(E); j < JNT_HI(E); j++)
       if (jnt_stiffness[j] != 0 &&
           (jnt_type[j] == JNT_SLIDE || jnt_type[j] == JNT_HINGE)) {
         const int qa = jnt_qposadr[j];
@@ -1521,7 +1560,7 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
             R(jnt_stiffness[j])*(E.qpos[qa] - R(qpos_spring[qa]));
       }
     DMC_UNROLL
-    for (int i = 0; i < NV; i++)
+    for (int i = DOF_LO(E); i < DOF_HI(E); i++)
       E.qfrc_smooth[i] -= R(dof_damping[i])*E.qvel[i];
   }
   if (actuation && !(DISABLEFLAGS & DSBL_ACTUATION)) {
@@ -1529,6 +1568,10 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
     // tendon wraps; the point-mass task varies the coefficients per instance
     DMC_UNROLL
     for (int i = 0; i < NU; i++) {
+      if (TEAMED) {       // the actuators of this lane's tree (an actuator acts inside one tree)
+        const int d = act_wrap_dof[act_wrap_adr[i]];
+        if (d < DOF_LO(E) || d >= DOF_HI(E)) continue;
+      }
       const real gear = R(actuator_gear[i]);
       real c = E.ctrl[i];
       if (actuator_ctrllimited[i] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
@@ -1555,21 +1598,16 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
       }
     }
   }
+  if (TEAMED) return;        // (forward_team() solves for qacc_smooth once M is factored)
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qacc_smooth[i] = E.qfrc_smooth[i];
-  if (TEAMED) {
-    real* x = W.lds + TL_X;
-    team_put(x, E.qacc_smooth);
-    team_solve(W, x, Mats::L(E, W), nullptr, 0u);
-    team_take(E.qacc_smooth, x);
-  }
-  else if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
+  if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
   else chol_solve(E.qacc_smooth, Mats::L(E, W));
 }
 
 DEV void subtree_vel(Env& E) {
   DMC_UNROLL
-  for (int i = 0; i < NBODY; i++) {
+  for (int i = BODY_LO0(E); i < BODY_HI(E); i++) {
     real dif[3], t[3];
     const real* com = E.subtree_com + 3*body_rootid[i];
     DMC_UNROLL
@@ -1580,12 +1618,12 @@ DEV void subtree_vel(Env& E) {
       E.subtree_linvel[3*i + k] = R(body_mass[i])*(E.cvel[6*i + 3 + k] + t[k]);
   }
   DMC_UNROLL
-  for (int i = NBODY - 1; i > 0; i--)
+  for (int i = BODY_HI(E) - 1; i >= BODY_LO(E); i--)
     DMC_UNROLL
     for (int k = 0; k < 3; k++)
       E.subtree_linvel[3*body_parentid[i] + k] += E.subtree_linvel[3*i + k];
   DMC_UNROLL
-  for (int i = 0; i < NBODY; i++) {
+  for (int i = BODY_LO0(E); i < BODY_HI(E); i++) {
     real inv = R(1.0/(body_subtreemass[i] < 1e-15 ? 1e-15 : body_subtreemass[i]));
     DMC_UNROLL
     for (int k = 0; k < 3; k++) E.subtree_linvel[3*i + k] *= inv;
@@ -2882,7 +2920,6 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
   const int tl = tlane();
-  for (int i = tl; i < NV; i += TEAM) { q[i] = E.qacc[i]; fs[i] = E.qfrc_smooth[i]; }
   // envelope of the Hessian: M's, widened by the rows whose dofs lie in two trees
   // (LDS ints); bit t of `coupled`: tree t has rows that start left of it
   int* const hlo = reinterpret_cast<int*>(W.lds + TL_HLO);
@@ -3080,9 +3117,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     alpha_prev = alpha;
     tsync();
   }
-  tsync();
-  for (int i = 0; i < NV; i++) { E.qacc[i] = q[i]; E.qfrc_constraint[i] = fc[i]; }
-  tsync();
+  tsync();        // (E.qacc and E.qfrc_constraint ARE q and fc in team mode)
   E.iters = iter;
 }
 
@@ -3197,7 +3232,162 @@ DEV void touch_sensors(Env& E, const Work& W) {
 #else
 #define FPROF(k) do {} while (0)
 #endif
+// ---------------------------------------------------------------------------
+// Team mode: one forward pass.  Phase 1 -- the tree recursions on one lane per
+// tree (NGROUPS trees at a time), then limits and contacts with the whole team;
+// phase 2 -- the linear algebra (factor of M, qacc_smooth, warm start, Newton).
+// ---------------------------------------------------------------------------
+constexpr int NGROUPS = TEAM >= 8 ? 4 : (TEAM >= 2 ? TEAM/2 : 1);
+constexpr int LANES_PER_GROUP = TEAM/NGROUPS;
+#ifdef DMC_TEAM
+DEV void team_bind(Env& E, const Work& W) {
+  E.xpos = W.lds + TL_XPOS; E.xquat = W.lds + TL_XQUAT; E.xmat = W.lds + TL_XMAT;
+  E.subtree_com = W.lds + TL_SCOM; E.cdof = W.lds + TL_CDOF;
+  E.qfrc_smooth = W.lds + TL_FS; E.qfrc_constraint = W.lds + TL_FC;
+  E.qacc_smooth = W.lds + TL_QAS; E.qacc = W.lds + TL_Q;
+  E.rb0 = 1; E.rb1 = NBODY; E.rj0 = 0; E.rj1 = NJNT; E.rd0 = 0; E.rd1 = NV;
+}
+DEV void team_range(Env& E, int t) {
+  E.rb0 = tree_body_lo[t]; E.rb1 = tree_body_hi[t];
+  E.rj0 = tree_jnt_lo[t]; E.rj1 = tree_jnt_hi[t];
+  E.rd0 = tree_dof_lo[t]; E.rd1 = tree_dof_hi[t];
+}
+DEV void team_range_all(Env& E) {
+  E.rb0 = 1; E.rb1 = NBODY; E.rj0 = 0; E.rj1 = NJNT; E.rd0 = 0; E.rd1 = NV;
+}
+#else
+DEV void team_bind(Env&, const Work&) {}
+DEV void team_range(Env&, int) {}
+DEV void team_range_all(Env&) {}
+#endif
+static_assert(!TEAMED || NTOUCH == 0, "team mode: touch sensors read frames after the solver");
+
+// joint limits, a chunk of TEAM limits at a time; rows in the serial order
+DEV void limit_rows_team(Env& E, const Work& W) {
+  if (DISABLEFLAGS & (DSBL_LIMIT | DSBL_CONSTRAINT)) return;
+  const int tl = tlane();
+  for (int l0 = 0; l0 < NLIMIT; l0 += TEAM) {
+    const int l = l0 + tl;
+    int cnt = 0;
+    real pm[2] = {0, 0};
+    bool on[2] = {false, false};
+    int j = 0, dof = 0;
+    if (l < NLIMIT) {
+      j = limit_jnt[l]; dof = jnt_dofadr[j];
+      const real margin = R(jnt_margin[j]);
+      const real q = E.qpos[jnt_qposadr[j]];
+      const real d0 = q - R(jnt_range[2*j]), d1 = R(jnt_range[2*j + 1]) - q;
+      if (d0 < margin) { on[0] = true; pm[0] = d0 - margin; cnt++; }
+      if (d1 < margin) { on[1] = true; pm[1] = d1 - margin; cnt++; }
+    }
+    int total;
+    const int first = E.nefc, at = tscan(cnt, total);
+    if (cnt > 0) {
+      E.nefc = first + at;
+      for (int sd = 0; sd < 2; sd++) {
+        if (!on[sd]) continue;
+        const real imp = impedance(limit_solimp + 5*l, pm[sd]);
+        const real Rr = (1 - imp)*R(dof_invweight0[dof])/imp;
+        push_row_1(E, W, dof, sd == 0 ? R(1) : R(-1), pm[sd], R(limit_K[l]), R(limit_B[l]), imp, Rr);
+      }
+    }
+    E.warn = tor(E.warn);
+    E.nefc = first + total < NEFC_MAX ? first + total : NEFC_MAX;
+  }
+  tsync();
+}
+
+DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth);
+DEV void forward_team(Env& E, const Work& W, bool actuation, real tol) {
+#ifdef DMC_STEP_PROFILE
+  long long tf_ = wall_clock64();
+#endif
+  const int tl = tlane();
+  const auto M = Mats::M(E, W);
+  const auto L = Mats::L(E, W);
+  real* const x = W.lds + TL_X;
+  real* const q = W.lds + TL_Q;
+  real* const Ma = W.lds + TL_MA;
+  real* const fs = W.lds + TL_FS;
+  real* const fc = W.lds + TL_FC;
+  real* const qas = W.lds + TL_QAS;
+  // the rows of M inside the trees' envelope start from zero
+  for (int i = 0; i < NV; i++)
+    for (int j = dof_treeroot[i] + tl; j <= i; j += TEAM) M.set(tri(i, j), 0);
+  tsync();
+  if (tl % LANES_PER_GROUP == 0) {
+    for (int t = tl/LANES_PER_GROUP; t < NTREE; t += NGROUPS) {
+      team_range(E, t);
+      kinematics(E);
+      com_pos(E);
+      com_vel(E);
+      crb_tree(E, W);
+      smooth_forces(E, W, actuation);
+    }
+    team_range_all(E);
+  }
+  tsync();
+  FPROF(0);
+  E.ncon = 0; E.nefc = 0; E.iters = 0; E.nmerged = 0;
+  limit_rows_team(E, W);
+  E.nefc_limit = E.nefc;
+  FPROF(3);
+  if (NPAIR > 0) contact_rows(E, W);
+  FPROF(4);
+  // ---- phase 2 (the frames in LDS are dead from here on)
+  if (team_factor(W, L, M, nullptr, 0u, R(0), false, FlipList{nullptr, -1}, false, 0, L))
+    E.warn |= WARN_INERTIA;
+  FPROF(1);
+  for (int i = tl; i < NV; i += TEAM) { qas[i] = fs[i]; fc[i] = 0; }
+  tsync();
+  team_solve(W, qas, L, nullptr, 0u);
+  FPROF(2);
+  if (E.nefc == 0) {
+    for (int i = tl; i < NV; i += TEAM) q[i] = qas[i];
+    tsync();
+  } else {
+    // warmstart: better of previous qacc and the unconstrained acceleration;
+    // Jaref of both candidates in one pass (warm -> ROW_JAR, smooth -> ROW_JV)
+    const bool try_warm = !(DISABLEFLAGS & DSBL_WARMSTART);
+    real cw = 0, cs = 0;
+    team_put(x, E.warm);
+    if (try_warm) {
+      team_symv(W, Ma, M, x);
+      real c = 0;
+      for (int i = tl; i < NV; i += TEAM) c += R(0.5)*(Ma[i] - fs[i])*(x[i] - qas[i]);
+      cw = tsum(c);
+    }
+    real rw = 0, rs = 0;
+    for (int r = tl; r < E.nefc; r += TEAM) {
+      const auto rec = W.grow(r);
+      const int jlo = (int)rec.get(ROW_LO), jhi = (int)rec.get(ROW_HI);
+      const real aref = rec.get(ROW_AREF), D = rec.get(ROW_D);
+      real jw = 0, js = 0;
+      int j = jlo;
+      for (; j + 8 <= jhi + 1; j += 8) {
+        real a[8];
+        _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = rec.get(j + u);
+        _Pragma("unroll") for (int u = 0; u < 8; u++) { jw += a[u]*x[j + u]; js += a[u]*qas[j + u]; }
+      }
+      for (; j <= jhi; j++) { const real a = rec.get(j); jw += a*x[j]; js += a*qas[j]; }
+      jw -= aref; js -= aref;
+      if (jw < 0) rw += R(0.5)*D*jw*jw;
+      if (js < 0) rs += R(0.5)*D*js*js;
+      rec.set(ROW_JAR, jw); rec.set(ROW_JV, js);
+    }
+    cw += tsum(rw); cs += tsum(rs);
+    tsync();
+    const bool use_warm = try_warm && !(cw > cs);
+    for (int i = tl; i < NV; i += TEAM) q[i] = use_warm ? x[i] : qas[i];
+    tsync();
+    solve_newton_team(E, W, tol, !use_warm);
+  }
+  FPROF(5);
+  for (int i = 0; i < NV; i++) E.warm[i] = q[i];
+}
+
 DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
+  if (TEAMED) { forward_team(E, W, actuation, tol); return; }
 #ifdef DMC_STEP_PROFILE
   long long tf_ = wall_clock64();
 #endif
@@ -3406,10 +3596,10 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
       const auto M = Mats::M(E, W);
       const LaneMat A = Mats::local(Areg, W, MAT_A);
       if (TEAMED) {
-        for (int i = 0; i < NV; i++) qacc[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
-        team_factor(W, A, M, nullptr, 0u, h, false, FlipList{nullptr, -1}, false, 0, A);
         real* x = W.lds + TL_X;
-        team_put(x, qacc);
+        for (int i = tlane(); i < NV; i += TEAM) x[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
+        tsync();
+        team_factor(W, A, M, nullptr, 0u, h, false, FlipList{nullptr, -1}, false, 0, A);
         team_solve(W, x, A, nullptr, 0u);
         team_take(qacc, x);
       } else {
@@ -3507,6 +3697,11 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
 // mj_step1 that the observation needs)
 DEV void observe_stage(Env& E, real& time) {
   check_state(E, time);
+  if (TEAMED) {                 // the recursions of all trees on lane 0 (frames land in LDS)
+    if (tlane() == 0) { kinematics(E); com_pos(E); com_vel(E); subtree_vel(E); }
+    tsync();
+    return;
+  }
   kinematics(E);
   com_pos(E);
   com_vel(E);
@@ -3911,6 +4106,7 @@ dmc_step(DmcArgs a) {
   const Work W = TEAMED
       ? Work{lds_rows + (threadIdx.x/TEAM)*TEAM_LDS_WORDS, a.ws + (long long)e*WS_WORDS, 1}
       : Work{lds_rows + threadIdx.x, a.ws + e, n};
+  team_bind(E, W);
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
   for (int s = 0; s < a.nsub; s++)
     physics_step(E, W, time, tol, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
@@ -3920,7 +4116,10 @@ dmc_step(DmcArgs a) {
   }
   if (!(a.flags & 2)) {
 #ifndef DMC_ABLATE_OBS
-    observe_stage(E, time);
+    // (a model without a task: the observation is qpos and qvel; the frames are
+    // only recomputed if someone reads them)
+    if (TASK == TASK_NONE && NSENSOR == 0 && NTOUCH == 0 && !a.xpos && !a.xmat) check_state(E, time);
+    else observe_stage(E, time);
 #endif
     store_outputs(E, a, e, true, lds_rows);
   }
@@ -3949,6 +4148,7 @@ dmc_observe(DmcArgs a) {
   const Work W = TEAMED
       ? Work{lds_rows + (threadIdx.x/TEAM)*TEAM_LDS_WORDS, a.ws + (long long)e*WS_WORDS, 1}
       : Work{lds_rows + threadIdx.x, a.ws + e, n};
+  team_bind(E, W);
   if (NTOUCH > 0) {
     // acceleration-stage sensors need the constraint forces: the reference's
     // after_reset runs mj_forward with actuation disabled (engine.py:283-295);

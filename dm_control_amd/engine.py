@@ -453,6 +453,11 @@ class Physics(_control.Physics):
     if info.lanes_per_env > 64:
       return ('64 lanes per env + a second wavefront building the constraint '
               'rows (csrc/dmc_coop.hip)')
+    if info.lanes_per_env > 1 and not info.env_major:
+      # (only the team build of csrc/dmc_kernels.hip keeps [k][env] state with
+      # several lanes per env)
+      return ('one wavefront per env, matrices in the HBM workspace, a tree\'s block '
+              'at a time in LDS (csrc/dmc_kernels.hip, team mode)')
     if info.lanes_per_env > 1:
       return '%d lanes per env (csrc/dmc_coop.hip)' % info.lanes_per_env
     return 'one env per lane (csrc/dmc_kernels.hip)'
