@@ -587,7 +587,8 @@ DEV void copy_env(const Mat& dst, const Mat& src, const Lo& lo, const SLo& slo) 
 #define DOF_HI(E) NV
 #endif
 struct Env {
-  real qpos[NQ > 0 ? NQ : 1], qvel[NVX], ctrl[NUX], warm[NVX];
+  DMC_SHARED(qpos, NQ > 0 ? NQ : 1); DMC_SHARED(qvel, NVX); DMC_SHARED(warm, NVX);
+  real ctrl[NUX];
 #ifdef DMC_STATE_COMP
   real qpos_lo[NQ > 0 ? NQ : 1], qvel_lo[NVX];   // low words of the fp64 state
 #endif
@@ -710,7 +711,8 @@ constexpr int TSTR = TB + 1;
 constexpr int TL_VEC = 0, TL_X = TL_VEC + 2*NVX, TL_Q = TL_X + NVX, TL_MA = TL_Q + NVX,
               TL_MV = TL_MA + NVX, TL_FS = TL_MV + NVX, TL_FC = TL_FS + NVX, TL_QAS = TL_FC + NVX,
               TL_ROW = TL_QAS + NVX, TL_HLO = TL_ROW + (NVX > 4*TB ? NVX : 4*TB),
-              TL_PHASE = TL_HLO + NVX;
+              TL_QPOS = TL_HLO + NVX, TL_QVEL = TL_QPOS + (NQ > 0 ? NQ : 1), TL_WARM = TL_QVEL + NVX,
+              TL_PHASE = TL_WARM + NVX;
 // What follows is used in two phases of a step that do not overlap.  Phase 2
 // (linear algebra): the tile and the list of pending Hessian changes.
 constexpr int TL_TILE = TL_PHASE, TL_FLIPS = TL_TILE + TB*TSTR, TL_END2 = TL_FLIPS + 4*256;
@@ -1127,8 +1129,74 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hl
   }
   return nbad;
 }
-// x <- F^-T F^-1 x, tile by tile: the tree's block of the factor in LDS, column
-// substitutions with one row per lane
+// Triangular solves with the tile in LDS: row ii = tl + m*TEAM of the right-hand
+// side lives in a register of lane tl (one row per lane on the GPU), the pivot
+// row's value reaches the others through a lane broadcast, and the column of the
+// tile that the next step needs is requested one step ahead -- the dependence
+// chain per column is one broadcast and one multiply-add.
+DEV void tile_forward(const real* T, real* x, int n) {
+  const int tl = tlane();
+  real xv[KPL], dg[KPL], col[KPL];
+  _Pragma("unroll")
+  for (int m = 0; m < KPL; m++) {
+    const int ii = tl + m*TEAM;
+    xv[m] = ii < n ? x[ii] : R(0);
+    dg[m] = ii < n ? T[ii*TSTR + ii] : R(1);
+    col[m] = (ii < n && ii > 0) ? T[ii*TSTR] : R(0);
+  }
+  for (int j = 0; j < n; j++) {
+    const int oj = j & (TEAM - 1), sj = j/TEAM;
+    const real xj = tget(KPL == 1 ? xv[0] : xv[sj], oj)*tget(KPL == 1 ? dg[0] : dg[sj], oj);
+    real nxt[KPL];
+    _Pragma("unroll")
+    for (int m = 0; m < KPL; m++) {
+      const int ii = tl + m*TEAM;
+      nxt[m] = (ii < n && ii > j + 1) ? T[ii*TSTR + j + 1] : R(0);
+    }
+    _Pragma("unroll")
+    for (int m = 0; m < KPL; m++) {
+      const int ii = tl + m*TEAM;
+      if (ii == j) xv[m] = xj;
+      else if (ii > j) xv[m] -= col[m]*xj;
+      col[m] = nxt[m];
+    }
+  }
+  _Pragma("unroll")
+  for (int m = 0; m < KPL; m++) { const int ii = tl + m*TEAM; if (ii < n) x[ii] = xv[m]; }
+  tsync();
+}
+DEV void tile_backward(const real* T, real* x, int n) {
+  const int tl = tlane();
+  real xv[KPL], dg[KPL], row[KPL];
+  _Pragma("unroll")
+  for (int m = 0; m < KPL; m++) {
+    const int kk = tl + m*TEAM;
+    xv[m] = kk < n ? x[kk] : R(0);
+    dg[m] = kk < n ? T[kk*TSTR + kk] : R(1);
+    row[m] = kk < n - 1 ? T[(n - 1)*TSTR + kk] : R(0);
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    const int oi = i & (TEAM - 1), si = i/TEAM;
+    const real xi = tget(KPL == 1 ? xv[0] : xv[si], oi)*tget(KPL == 1 ? dg[0] : dg[si], oi);
+    real nxt[KPL];
+    _Pragma("unroll")
+    for (int m = 0; m < KPL; m++) {
+      const int kk = tl + m*TEAM;
+      nxt[m] = (i > 0 && kk < i - 1) ? T[(i - 1)*TSTR + kk] : R(0);
+    }
+    _Pragma("unroll")
+    for (int m = 0; m < KPL; m++) {
+      const int kk = tl + m*TEAM;
+      if (kk == i) xv[m] = xi;
+      else if (kk < i) xv[m] -= row[m]*xi;
+      row[m] = nxt[m];
+    }
+  }
+  _Pragma("unroll")
+  for (int m = 0; m < KPL; m++) { const int kk = tl + m*TEAM; if (kk < n) x[kk] = xv[m]; }
+  tsync();
+}
+// x <- F^-T F^-1 x, tile by tile: the tree's block of the factor in LDS
 template <class Mat>
 DEV void team_solve(const Work& W, real* x, const Mat& F, const int* hlo, unsigned coupled) {
   real* T = W.lds + TL_TILE;
@@ -1153,24 +1221,12 @@ DEV void team_solve(const Work& W, real* x, const Mat& F, const int* hlo, unsign
       }
       tsync();
     }
-    for (int j = 0; j < n; j++) {
-      const real xj = x[s + j]*T[j*TSTR + j];
-      tsync();
-      if (tl == 0) x[s + j] = xj;
-      for (int ii = j + 1 + tl; ii < n; ii += TEAM) x[s + ii] -= T[ii*TSTR + j]*xj;
-      tsync();
-    }
+    tile_forward(T, x + s, n);
   }
   for (int t = NDTREE - 1; t >= 0; t--) {
     const int s = dtree_lo[t], e = dtree_hi[t], n = e - s + 1;
     tile_load(T, F, s, n);
-    for (int i = n - 1; i >= 0; i--) {
-      const real xi = x[s + i]*T[i*TSTR + i];
-      tsync();
-      if (tl == 0) x[s + i] = xi;
-      for (int k = tl; k < i; k += TEAM) x[s + k] -= T[i*TSTR + k]*xi;
-      tsync();
-    }
+    tile_backward(T, x + s, n);
     if ((coupled >> t) & 1u) {            // the coupled rows push their values into the earlier trees
       for (int i = s; i <= e; i++) {
         const int li = hlo[i];
@@ -3245,6 +3301,7 @@ DEV void team_bind(Env& E, const Work& W) {
   E.subtree_com = W.lds + TL_SCOM; E.cdof = W.lds + TL_CDOF;
   E.qfrc_smooth = W.lds + TL_FS; E.qfrc_constraint = W.lds + TL_FC;
   E.qacc_smooth = W.lds + TL_QAS; E.qacc = W.lds + TL_Q;
+  E.qpos = W.lds + TL_QPOS; E.qvel = W.lds + TL_QVEL; E.warm = W.lds + TL_WARM;
   E.rb0 = 1; E.rb1 = NBODY; E.rj0 = 0; E.rj1 = NJNT; E.rd0 = 0; E.rd1 = NV;
 }
 DEV void team_range(Env& E, int t) {
@@ -3383,7 +3440,8 @@ DEV void forward_team(Env& E, const Work& W, bool actuation, real tol) {
     solve_newton_team(E, W, tol, !use_warm);
   }
   FPROF(5);
-  for (int i = 0; i < NV; i++) E.warm[i] = q[i];
+  for (int i = tl; i < NV; i += TEAM) E.warm[i] = q[i];
+  tsync();
 }
 
 DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
@@ -3485,7 +3543,7 @@ DEV void forward(Env& E, const Work& W, bool actuation, real tol) {
 
 DEV void integrate_pos(real* qpos, const real* qvel, real h) {
   DMC_UNROLL
-  for (int j = 0; j < NJNT; j++) {
+  for (int j = TEAMED ? tlane() : 0; j < NJNT; j += TEAM) {     // (team mode: a joint per lane)
     const int qa = jnt_qposadr[j], da = jnt_dofadr[j];
     if (jnt_type[j] == JNT_FREE) {
       DMC_UNROLL
@@ -3538,10 +3596,17 @@ DEV void integrate_comp(Env& E, const real* v0, const real* v0_lo, const real* q
 #endif
 
 DEV void reset_state(Env& E, real& time) {   // mj_resetData
+  if (TEAMED) {
+    tsync();
+    for (int i = tlane(); i < NQ; i += TEAM) E.qpos[i] = R(qpos0[i]);
+    for (int i = tlane(); i < NV; i += TEAM) { E.qvel[i] = 0; E.warm[i] = 0; }
+    tsync();
+  } else {
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) E.qpos[i] = R(qpos0[i]);
   DMC_UNROLL
   for (int i = 0; i < NV; i++) { E.qvel[i] = 0; E.warm[i] = 0; }
+  }
   DMC_UNROLL
   for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
 #ifdef DMC_STATE_COMP
@@ -3554,10 +3619,16 @@ DEV void reset_state(Env& E, real& time) {   // mj_resetData
 }
 DEV bool check_state(Env& E, real& time) {   // mj_checkPos / mj_checkVel
   bool bp = false, bv = false;
+  if (TEAMED) {
+    for (int i = tlane(); i < NQ; i += TEAM) bp |= bad(E.qpos[i]);
+    for (int i = tlane(); i < NV; i += TEAM) bv |= bad(E.qvel[i]);
+    bp = tany(bp); bv = tany(bv);
+  } else {
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) bp |= bad(E.qpos[i]);
   DMC_UNROLL
   for (int i = 0; i < NV; i++) bv |= bad(E.qvel[i]);
+  }
   if (bp) { E.warn |= WARN_BADQPOS; reset_state(E, time); }
   else if (bv) { E.warn |= WARN_BADQVEL; reset_state(E, time); }
   return bp || bv;
@@ -3574,6 +3645,35 @@ DEV bool check_state(Env& E, real& time) {   // mj_checkPos / mj_checkVel
 DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = false) {
   const real h = R(timestep);
   check_state(E, time);
+  static_assert(!TEAMED || INTEGRATOR == 0, "team mode: semi-implicit Euler");
+  if (TEAMED) {
+    // every vector is shared (LDS): the lanes split the dofs and the joints
+    const int tl = tlane();
+    forward(E, W, true, tol);
+    bool ba = false;
+    for (int i = tl; i < NV; i += TEAM) ba |= bad(E.qacc[i]);
+    if (tany(ba)) { E.warn |= WARN_BADQACC; reset_state(E, time); return; }
+    bool damped = false;
+    for (int i = 0; i < NV; i++) damped |= dof_damping[i] > 0;
+    real* x = W.lds + TL_X;
+    if (damped) {
+      const auto M = Mats::M(E, W);
+      const auto A = Mats::local(nullptr, W, MAT_A);
+      for (int i = tl; i < NV; i += TEAM) x[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
+      tsync();
+      team_factor(W, A, M, nullptr, 0u, h, false, FlipList{nullptr, -1}, false, 0, A);
+      team_solve(W, x, A, nullptr, 0u);
+    } else {
+      for (int i = tl; i < NV; i += TEAM) x[i] = E.qacc[i];
+      tsync();
+    }
+    for (int i = tl; i < NV; i += TEAM) E.qvel[i] += h*x[i];
+    tsync();
+    integrate_pos(E.qpos, E.qvel, h);
+    tsync();
+    time += h;
+    return;
+  }
   if (INTEGRATOR == 0) {
     real qkeep[NQ > 0 ? NQ : 1], vkeep[NVX];
     if (stale) {
@@ -3595,14 +3695,7 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
       real Areg[MAT_REGS];
       const auto M = Mats::M(E, W);
       const LaneMat A = Mats::local(Areg, W, MAT_A);
-      if (TEAMED) {
-        real* x = W.lds + TL_X;
-        for (int i = tlane(); i < NV; i += TEAM) x[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
-        tsync();
-        team_factor(W, A, M, nullptr, 0u, h, false, FlipList{nullptr, -1}, false, 0, A);
-        team_solve(W, x, A, nullptr, 0u);
-        team_take(qacc, x);
-      } else {
+      {
       if (MAT_IN_WS) copy_env(A, M, LoTree{}, LoTree{});
       else {
         DMC_UNROLL
@@ -3954,10 +4047,16 @@ DEV real task_outputs(const EnvT& E, const DmcArgs& a, real* obs) {
 #ifndef DMC_COOP_BUILD
 DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
   const long long n = a.nenv;
+  if (TEAMED) {       // the shared state: every lane fetches its share
+    for (int i = tlane(); i < NQ; i += TEAM) E.qpos[i] = a.qpos[i*n + e];
+    for (int i = tlane(); i < NV; i += TEAM) { E.qvel[i] = a.qvel[i*n + e]; E.warm[i] = a.warm[i*n + e]; }
+    tsync();
+  } else {
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) E.qpos[i] = a.qpos[i*n + e];
   DMC_UNROLL
   for (int i = 0; i < NV; i++) { E.qvel[i] = a.qvel[i*n + e]; E.warm[i] = a.warm[i*n + e]; }
+  }
   time = a.time[e];
 #ifdef DMC_STATE_COMP
   {
@@ -3991,7 +4090,16 @@ DEV void load_env(Env& E, const DmcArgs& a, int e, real& time) {
 }
 DEV void store_env(const Env& E, const DmcArgs& a, int e, real time) {
   const long long n = a.nenv;
-  if (TEAMED && tlane() != 0) return;      // every lane holds the same state
+  if (TEAMED) {
+    tsync();
+    for (int i = tlane(); i < NQ; i += TEAM) a.qpos[i*n + e] = E.qpos[i];
+    for (int i = tlane(); i < NV; i += TEAM) { a.qvel[i*n + e] = E.qvel[i]; a.warm[i*n + e] = E.warm[i]; }
+    if (tlane() == 0) {
+      a.time[e] = time;
+      if (E.warn) a.warn[e] |= E.warn;
+    }
+    return;
+  }
   DMC_UNROLL
   for (int i = 0; i < NQ; i++) a.qpos[i*n + e] = E.qpos[i];
   DMC_UNROLL
@@ -4082,8 +4190,13 @@ dmc_step(DmcArgs a) {
   if (e >= a.nenv) return;                 // (team mode: a team leaves together)
   Env E;
   real time;
-  load_env(E, a, e, time);
   const long long n = a.nenv;
+  __shared__ real lds_rows[TEAMED ? TEAM_LDS_WORDS*(LANES/TEAM) : LDS_WORDS];
+  const Work W = TEAMED
+      ? Work{lds_rows + (threadIdx.x/TEAM)*TEAM_LDS_WORDS, a.ws + (long long)e*WS_WORDS, 1}
+      : Work{lds_rows + threadIdx.x, a.ws + e, n};
+  team_bind(E, W);
+  load_env(E, a, e, time);
   if (a.flags & 1) {
     bool bc = false;
     DMC_UNROLL
@@ -4102,11 +4215,6 @@ dmc_step(DmcArgs a) {
     DMC_UNROLL
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
-  __shared__ real lds_rows[TEAMED ? TEAM_LDS_WORDS*(LANES/TEAM) : LDS_WORDS];
-  const Work W = TEAMED
-      ? Work{lds_rows + (threadIdx.x/TEAM)*TEAM_LDS_WORDS, a.ws + (long long)e*WS_WORDS, 1}
-      : Work{lds_rows + threadIdx.x, a.ws + e, n};
-  team_bind(E, W);
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
   for (int s = 0; s < a.nsub; s++)
     physics_step(E, W, time, tol, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
@@ -4140,15 +4248,15 @@ dmc_observe(DmcArgs a) {
   if (e >= a.nenv) return;                 // (team mode: a team leaves together)
   Env E;
   real time;
-  load_env(E, a, e, time);
   const long long n = a.nenv;
-  DMC_UNROLL
-  for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   __shared__ real lds_rows[TEAMED ? TEAM_LDS_WORDS*(LANES/TEAM) : LDS_WORDS];
   const Work W = TEAMED
       ? Work{lds_rows + (threadIdx.x/TEAM)*TEAM_LDS_WORDS, a.ws + (long long)e*WS_WORDS, 1}
       : Work{lds_rows + threadIdx.x, a.ws + e, n};
   team_bind(E, W);
+  load_env(E, a, e, time);
+  DMC_UNROLL
+  for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   if (NTOUCH > 0) {
     // acceleration-stage sensors need the constraint forces: the reference's
     // after_reset runs mj_forward with actuation disabled (engine.py:283-295);

@@ -6,3 +6,8 @@ echo "pytest rc=$rc"; grep -E "OBSERVED|passed|failed|Error|error" $O/pitch_test
 [ $rc -eq 0 ] || exit 1
 timeout -k 10 300 python tools/debug/pitch_profile.py loud --team > $O/pitch_profile_team_loud.txt 2>&1 && cat $O/pitch_profile_team_loud.txt &&
 timeout -k 10 300 python tools/debug/pitch_profile.py loud --team --f64 > $O/pitch_profile_team_loud_f64.txt 2>&1 && cat $O/pitch_profile_team_loud_f64.txt
+timeout -k 10 600 python bench.py --domain soccer --task 2v2 --batch 1024 --steps 20 --warmup 3 --no-compliant-leg > $O/bench_soccer_team.json 2> $O/bench_soccer_team.err; echo bench rc=$?; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r03g/bench_soccer_team.json').read().strip().splitlines()[-1])
+print('bench', d['value'], 'env-steps/s', d['ms_per_step'], 'ms/step kernel', d['roofline'].get('kernel_ms_avg'), 'cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('qpos_rel_err',{}).get('teacher_forced'))
+PY
