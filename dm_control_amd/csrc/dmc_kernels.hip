@@ -885,7 +885,35 @@ DEV void tile_store(const Mat& A, const real* T, int s, int n) {
 // in place T = L L^T (lower part), the diagonal keeps the inverse pivots.  One
 // row per lane; the update of a row runs eight columns at a time so that the LDS
 // round trips of a block overlap.
+// With a whole wavefront per env (TEAM = 64) the factorisation never touches
+// memory: lane i keeps row i of the tile in registers, the pivot and the
+// multipliers of a column travel by lane broadcast (straight-line code: register
+// indices must be constants).
+static __device__ __noinline__ int tile_factor_rows(real* T, int n) {     // (one copy: three call sites)
+  const int i = tlane();
+  real r[TB];
+  _Pragma("unroll")
+  for (int k = 0; k < TB; k++) r[k] = (i < n && k <= i) ? T[i*TSTR + k] : R(0);
+  int nbad = 0;
+  _Pragma("unroll")
+  for (int j = 0; j < TB; j++) {
+    if (j < n) {
+      real d = tget(r[j], j);
+      if (!(d >= DMC_MINVAL)) { d = DMC_MINVAL; nbad++; }
+      const real inv = rsqrt_(d);
+      const real lij = r[j]*inv;            // (meaningful in the lanes below the pivot)
+      _Pragma("unroll")
+      for (int k = j + 1; k < TB; k++) r[k] -= lij*tget(lij, k);   // (rows >= n are zero)
+      r[j] = i == j ? inv : lij;
+    }
+  }
+  _Pragma("unroll")
+  for (int k = 0; k < TB; k++) if (i < n && k <= i) T[i*TSTR + k] = r[k];
+  tsync();
+  return nbad;
+}
 DEV int tile_factor(real* T, int n) {
+  if (TEAM == TB) return tile_factor_rows(T, n);
   const int tl = tlane();
   int nbad = 0;
   for (int j = 0; j < n; j++) {
@@ -2976,6 +3004,9 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
   const real scale = R(1.0/(meaninertia*(NV > 1 ? NV : 1)));
   const int nefc = E.nefc;
   const int tl = tlane();
+#ifdef DMC_SOLVER_PROFILE
+  long long tl_ = wall_clock64();
+#endif
   // envelope of the Hessian: M's, widened by the rows whose dofs lie in two trees
   // (LDS ints); bit t of `coupled`: tree t has rows that start left of it
   int* const hlo = reinterpret_cast<int*>(W.lds + TL_HLO);
@@ -3075,6 +3106,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
       gn += g*g;
     }
     gn = tsum(gn);
+    SPROF(0);
     const bool converged = DMC_F32_RULES && iter > 0 && !changed &&
                            fabs(alpha_prev - 1) < R(1e-3);
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
@@ -3082,7 +3114,9 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     tsync();
     if (iter == 0) team_factor(W, F, M, henv, coupled, R(0), true, flips, true, nefc, H);
     else team_factor(W, F, H, henv, coupled, R(0), true, flips, false, nefc, H);
+    SPROF(1);
     team_solve(W, search, F, henv, coupled);
+    SPROF(2);
     real sn = 0;
     for (int i = tl; i < NV; i += TEAM) sn += search[i]*search[i];
     sn = sqrt(tsum(sn));
@@ -3096,6 +3130,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
       q2 += R(0.5)*search[i]*Mv[i];
     }
     q1 = tsum(q1); q2 = tsum(q2);
+    SPROF(3);
     // pass B: Jv and the line-search sums at alpha = 0 (and, fp32, at alpha = 1)
     LsPoint p0, p, best;
     {
@@ -3132,6 +3167,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
       p.d1 = p.d1 > DMC_MINVAL ? p.d1 : DMC_MINVAL;
     }
     tsync();
+    SPROF(4);
     if (!(p0.d0 < 0)) break;
     best = p0;
     real lo = 0, hi = 0, a = DMC_F32_RULES ? R(1) : -p0.d0/p0.d1;
@@ -3139,6 +3175,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
     for (int it = 0; it < DMC_LS_MAXIT; it++) {
       if (!(DMC_F32_RULES && it == 0)) {
+        SCOUNT(7);
         real dcost = 0, d0 = 0, d1 = 0;
         for (int r = tl; r < nefc; r += TEAM) {
           const auto rec = W.grow(r);
@@ -3167,8 +3204,10 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
       a = an;
     }
     const real alpha = best.alpha;
+    SPROF(5);
     if (alpha == 0) break;
     improvement = -best.dcost;
+    SCOUNT(6);
     for (int i = tl; i < NV; i += TEAM) { q[i] += alpha*search[i]; Ma[i] += alpha*Mv[i]; }
     alpha_prev = alpha;
     tsync();
