@@ -91,7 +91,45 @@ def collision_pairs(m):
             'collision between geom types %s is not implemented (geoms %r, %r)'
             % (key, m.names['geom'][g1], m.names['geom'][g2]))
       pairs.append((g1, g2))
-  return pairs
+  return _group_pairs_by_tree(m, pairs)
+
+
+def _trees_of(m):
+  """(root body ids, tree index of every body; -1: the world and what is welded to it)."""
+  roots = sorted(set(int(r) for r in m.body_rootid[1:])) or [0]
+  tree = [-1 if int(r) == 0 else roots.index(int(r)) for r in m.body_rootid]
+  if tree:
+    tree[0] = -1
+  return roots, tree
+
+
+def pair_run_key(m, tree, pair):
+  """What the pairs of one broadphase run share: two different trees, or a world
+  geom and a tree (None: pairs inside one tree, or between world geoms)."""
+  ta, tb = tree[int(m.geom_bodyid[pair[0]])], tree[int(m.geom_bodyid[pair[1]])]
+  if ta >= 0 and tb >= 0:
+    return ('tt', min(ta, tb), max(ta, tb)) if ta != tb else None
+  if ta < 0 and tb < 0:
+    return None
+  return ('wt', pair[0] if ta < 0 else pair[1], max(ta, tb))
+
+
+def _group_pairs_by_tree(m, pairs):
+  """Scenes of several kinematic trees (a soccer pitch): the pairs between the same
+  two trees, and between one world geom and one tree, become consecutive -- a
+  tree-level bounding test then skips a whole run at once.  (Geom order decided the
+  list before: a walker's 43 geoms against another walker's came in 43 runs.)
+  One-tree models keep the geom order."""
+  roots, tree = _trees_of(m)
+  ndof_trees = len(set(int(m.body_rootid[int(m.dof_bodyid[i])]) for i in range(m.nv)))
+  if ndof_trees < 2:
+    return pairs
+  def order(pair):
+    key = pair_run_key(m, tree, pair)
+    if key is None:       # inside a tree: by tree, after the rest
+      return (2, tree[int(m.geom_bodyid[pair[0]])], 0)
+    return (0, key[1], key[2]) if key[0] == 'wt' else (1, key[1], key[2])
+  return sorted(pairs, key=order)      # (stable: geom order inside a run)
 
 
 def mix_pair(m, g1, g2):
@@ -515,13 +553,15 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   ti('pair_tree2', [tree_of_body[int(m.geom_bodyid[p[1]])] for p in pairs] or [-1])
   # length of the run of consecutive pairs, from p on, between the same two
   # (different) trees: a far-apart pair of walkers skips the whole run at once
-  keys = [(tree_of_body[int(m.geom_bodyid[a])], tree_of_body[int(m.geom_bodyid[b])],
-           float(mx['margin'])) for (a, b), mx in zip(pairs, mixed)]
+  keys = [(pair_run_key(m, tree_of_body, pr), float(mx['margin']))
+          for pr, mx in zip(pairs, mixed)]
   run = [1]*len(pairs)
   for i in range(len(pairs) - 2, -1, -1):
-    if keys[i] == keys[i + 1] and keys[i][0] >= 0 and keys[i][1] >= 0 and keys[i][0] != keys[i][1]:
+    if keys[i] == keys[i + 1] and keys[i][0] is not None:
       run[i] = run[i + 1] + 1
   ti('pair_run', run or [1])
+  # the world geom of a world-vs-tree pair (-1: none): its bound against the tree's
+  ti('pair_wgeom', [k[0][1] if k[0] is not None and k[0][0] == 'wt' else -1 for k in keys] or [-1])
   ti('pair_b1', [int(m.geom_bodyid[p[0]]) for p in pairs])
   ti('pair_b2', [int(m.geom_bodyid[p[1]]) for p in pairs])
   ci('MAXCHAIN', maxchain)

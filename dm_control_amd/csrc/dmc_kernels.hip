@@ -715,7 +715,8 @@ constexpr int TL_VEC = 0, TL_X = TL_VEC + 2*NVX, TL_Q = TL_X + NVX, TL_MA = TL_Q
               TL_PHASE = TL_WARM + NVX;
 // What follows is used in two phases of a step that do not overlap.  Phase 2
 // (linear algebra): the tile and the list of pending Hessian changes.
-constexpr int TL_TILE = TL_PHASE, TL_FLIPS = TL_TILE + TB*TSTR, TL_END2 = TL_FLIPS + 4*256;
+constexpr int TL_TILE = TL_PHASE, TL_FLIPS = TL_TILE + TB*TSTR, TL_FLIP1 = TL_FLIPS + 4*256,
+              TL_END2 = TL_FLIP1 + 2*512;
 // Phase 1 (frames, forces, constraint rows): the geom-pose mirror the narrowphase
 // reads and the shared members of Env.
 constexpr int NGX_ = NGEOM > 0 ? NGEOM : 1;
@@ -985,9 +986,10 @@ DEV void team_coupled_tile(real* T, const Mat& F, const int* hlo, int s, int e) 
 // One pending change of the Hessian: row `r` (dofs lo..hi) enters or leaves with
 // weight w = +-D; a one-dof row (joint limit) carries w = +-D J^2 and is one
 // diagonal entry.  Pass A of the solver lists them in LDS (in row order).
-constexpr int NFLIP = 256;                  // beyond it: the rows are scanned (ROW_FLIP)
-static_assert(TL_END2 - TL_FLIPS == 4*NFLIP, "team LDS layout");
-struct FlipList { real* p; int n; };        // n < 0: not listed
+constexpr int NFLIP = 256, NFLIP1 = 512;    // beyond them: the rows are scanned (ROW_FLIP)
+static_assert(TL_FLIP1 - TL_FLIPS == 4*NFLIP && TL_END2 - TL_FLIP1 == 2*NFLIP1, "team LDS layout");
+// p: (row, lo, hi, w) of the rows with several dofs; p1: (dof, w) of the one-dof rows
+struct FlipList { real* p; int n; real* p1; int n1; };        // n < 0: not listed
 DEV void flip_apply_row(real* T, const real* seg, real w, int c0, int c1, int s) {
   const int tl = tlane();
   for (int j = c0; j <= c1; j++) {
@@ -1005,6 +1007,12 @@ DEV bool team_tile_flips_listed(real* T, const Work& W, const FlipList& L, int s
   const int tl = tlane();
   real* seg = W.lds + TL_ROW;
   bool any = false;
+  for (int f = tl; f < L.n1; f += TEAM) {          // the one-dof rows: one diagonal entry each
+    const int d = (int)L.p1[2*f];
+    if (d >= s && d <= e) { tatomic_add(T + (d - s)*TSTR + (d - s), L.p1[2*f + 1]); any = true; }
+  }
+  any = tany(any);
+  tsync();
   int f = 0;
   while (f < L.n) {
     int ids[4], c0s[4], c1s[4], cnt = 0;
@@ -1014,10 +1022,6 @@ DEV bool team_tile_flips_listed(real* T, const Work& W, const FlipList& L, int s
       const int lo = (int)q[1], hi = (int)q[2];
       if (hi < s || lo > e) continue;
       any = true;
-      if (lo == hi) {
-        if (tl == 0) T[(lo - s)*TSTR + (lo - s)] += q[3];
-        continue;
-      }
       ids[cnt] = (int)q[0]; ws[cnt] = q[3];
       c0s[cnt] = lo > s ? lo : s; c1s[cnt] = hi < e ? hi : e;
       cnt++;
@@ -1125,13 +1129,35 @@ DEV void team_cross_flips(const Mat& H, const Work& W, int nefc, const int* hlo,
     }
   }
 }
+// forward substitution, what the earlier trees contribute to the coupled rows of [s, e]
+template <class Mat>
+DEV void team_forward_coupled(real* x, const Mat& F, const int* hlo, int s, int e) {
+  for (int i = s + tlane(); i <= e; i += TEAM) {
+    const int li = hlo[i];
+    if (li >= s) continue;
+    const int bi = tri(i, 0);
+    real acc = 0;
+    int k = li;
+    for (; k + 8 <= s; k += 8) {
+      real a[8];
+      _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = F.get(bi + k + u);
+      _Pragma("unroll") for (int u = 0; u < 8; u++) acc += a[u]*x[k + u];
+    }
+    for (; k < s; k++) acc += F.get(bi + k)*x[k];
+    x[i] -= acc;
+  }
+  tsync();
+}
+DEV void tile_forward(const real* T, real* x, int n);
 // dst <- Cholesky factor of (src [+ h*damping on the diagonal] [+ pending row
 // changes]), tree by tree.  `flips`: the Newton Hessian -- the changed tiles
 // also go back to `H`, rows coupled to an earlier tree take their left parts from H.
+// `xfwd`: a right-hand side (shared vector) that takes the forward substitution
+// on the way (team_solve(..., forward_done = true) finishes it).
 template <class Mat>
 DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hlo,
                     unsigned coupled, real damping_h, bool flips, const FlipList& L,
-                    bool first, int nefc, const Mat& H) {
+                    bool first, int nefc, const Mat& H, real* xfwd = nullptr) {
   real* T = W.lds + TL_TILE;
   const int tl = tlane();
   int nbad = 0;
@@ -1153,6 +1179,10 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hl
       }
     }
     nbad += tile_factor(T, n);
+    if (xfwd) {       // the forward substitution of a right-hand side while the block is here
+      if ((coupled >> t) & 1u) team_forward_coupled(xfwd, dst, hlo, s, e);
+      tile_forward(T, xfwd + s, n);
+    }
     tile_store(dst, T, s, n);
   }
   return nbad;
@@ -1226,29 +1256,15 @@ DEV void tile_backward(const real* T, real* x, int n) {
 }
 // x <- F^-T F^-1 x, tile by tile: the tree's block of the factor in LDS
 template <class Mat>
-DEV void team_solve(const Work& W, real* x, const Mat& F, const int* hlo, unsigned coupled) {
+DEV void team_solve(const Work& W, real* x, const Mat& F, const int* hlo, unsigned coupled,
+                    bool forward_done = false) {
   real* T = W.lds + TL_TILE;
   const int tl = tlane();
+  if (!forward_done)
   for (int t = 0; t < NDTREE; t++) {
     const int s = dtree_lo[t], e = dtree_hi[t], n = e - s + 1;
     tile_load(T, F, s, n);
-    if ((coupled >> t) & 1u) {            // what the earlier trees contribute to the coupled rows
-      for (int i = s + tl; i <= e; i += TEAM) {
-        const int li = hlo[i];
-        if (li >= s) continue;
-        const int bi = tri(i, 0);
-        real acc = 0;
-        int k = li;
-        for (; k + 8 <= s; k += 8) {
-          real a[8];
-          _Pragma("unroll") for (int u = 0; u < 8; u++) a[u] = F.get(bi + k + u);
-          _Pragma("unroll") for (int u = 0; u < 8; u++) acc += a[u]*x[k + u];
-        }
-        for (; k < s; k++) acc += F.get(bi + k)*x[k];
-        x[i] -= acc;
-      }
-      tsync();
-    }
+    if ((coupled >> t) & 1u) team_forward_coupled(x, F, hlo, s, e);
     tile_forward(T, x + s, n);
   }
   for (int t = NDTREE - 1; t >= 0; t--) {
@@ -2416,16 +2432,32 @@ DEV void detect_contacts_team(Env& E, const Work& W) {
     if (reach > trad[t]) trad[t] = reach;
   }
   for (int t = 0; t < NTREE; t++) trad[t] = tmaxr(trad[t]);
+  // can no geom of the pair's tree(s) reach the other side?  Two trees: their
+  // bounding spheres; a world geom and a tree: the geom's bound (a plane: its
+  // half space) against the tree's sphere.
   auto far_apart = [&](int p) {
     const int t1 = pair_tree1[p], t2 = pair_tree2[p];
-    if (!(t1 >= 0 && t2 >= 0 && t1 != t2)) return false;
-    real d2 = 0;
-    for (int k = 0; k < 3; k++) {
-      const real d = tcen[3*t1 + k] - tcen[3*t2 + k];
-      d2 += d*d;
+    if (t1 >= 0 && t2 >= 0) {
+      if (t1 == t2) return false;
+      real d2 = 0;
+      for (int k = 0; k < 3; k++) {
+        const real d = tcen[3*t1 + k] - tcen[3*t2 + k];
+        d2 += d*d;
+      }
+      const real reach = trad[t1] + trad[t2] + R(pair_margin[p]);
+      return d2 > reach*reach;
     }
-    const real reach = trad[t1] + trad[t2] + R(pair_margin[p]);
-    return d2 > reach*reach;
+    const int wg = pair_wgeom[p];
+    if (wg < 0) return false;
+    const int t = t1 >= 0 ? t1 : t2;
+    real dif[3];
+    for (int k = 0; k < 3; k++) dif[k] = tcen[3*t + k] - G.get(12*wg + k);
+    if (geom_type[wg] == GEOM_PLANE) {
+      const real d = dif[0]*G.get(12*wg + 5) + dif[1]*G.get(12*wg + 8) + dif[2]*G.get(12*wg + 11);
+      return d > trad[t] + R(pair_margin[p]);
+    }
+    const real reach = trad[t] + R(geom_rbound[wg]) + R(pair_margin[p]);
+    return dot3(dif, dif) > reach*reach;
   };
   int p0 = 0;
   while (p0 < NPAIR) {
@@ -3037,7 +3069,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     tsync();
   }
   const int* const henv = coupled ? hlo : nullptr;
-  FlipList flips = {W.lds + TL_FLIPS, 0};
+  FlipList flips = {W.lds + TL_FLIPS, 0, W.lds + TL_FLIP1, 0};
   team_symv(W, Ma, M, q);
   real improvement = 0, alpha_prev = 0;
   int iter = 0;
@@ -3046,7 +3078,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     for (int i = tl; i < NV; i += TEAM) fc[i] = 0;
     tsync();
     bool changed = false;
-    flips.n = 0;
+    flips.n = 0; flips.n1 = 0;
     for (int r0 = 0; r0 < nefc; r0 += TEAM) {
       const int r = r0 + tl;
       bool flipped = false;
@@ -3085,19 +3117,24 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
         if (flo == fhi) { const real v = rec.get(flo); fw *= v*v; }
       }
       }
-      // the changes of this round, listed in row order
-      const unsigned long long fm = tballot(flipped);
-      if (flipped) {
-        const int at = flips.n + tpopc(fm & ((1ull << tl) - 1));
+      // the changes of this round, listed in row order (one-dof rows apart)
+      const bool one = flipped && flo == fhi;
+      const unsigned long long fm = tballot(flipped && !one), fm1 = tballot(one);
+      const unsigned long long below = (1ull << tl) - 1;
+      if (one) {
+        const int at = flips.n1 + tpopc(fm1 & below);
+        if (at < NFLIP1) { flips.p1[2*at] = (real)flo; flips.p1[2*at + 1] = fw; }
+      } else if (flipped) {
+        const int at = flips.n + tpopc(fm & below);
         if (at < NFLIP) {
           real* e = flips.p + 4*at;
           e[0] = (real)r; e[1] = (real)flo; e[2] = (real)fhi; e[3] = fw;
         }
       }
-      flips.n += tpopc(fm);
-      changed |= fm != 0;
+      flips.n += tpopc(fm); flips.n1 += tpopc(fm1);
+      changed |= (fm | fm1) != 0;
     }
-    if (flips.n > NFLIP) flips.n = -1;          // too many to list: team_factor scans the rows
+    if (flips.n > NFLIP || flips.n1 > NFLIP1) flips.n = -1;   // too many to list: team_factor scans the rows
     tsync();                      // fc, ROW_FLIP and ROW_JAR are read by other lanes from here on
     real gn = 0;
     for (int i = tl; i < NV; i += TEAM) {
@@ -3112,10 +3149,10 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
     tsync();
-    if (iter == 0) team_factor(W, F, M, henv, coupled, R(0), true, flips, true, nefc, H);
-    else team_factor(W, F, H, henv, coupled, R(0), true, flips, false, nefc, H);
+    if (iter == 0) team_factor(W, F, M, henv, coupled, R(0), true, flips, true, nefc, H, search);
+    else team_factor(W, F, H, henv, coupled, R(0), true, flips, false, nefc, H, search);
     SPROF(1);
-    team_solve(W, search, F, henv, coupled);
+    team_solve(W, search, F, henv, coupled, true);
     SPROF(2);
     real sn = 0;
     for (int i = tl; i < NV; i += TEAM) sn += search[i]*search[i];
@@ -3431,12 +3468,12 @@ DEV void forward_team(Env& E, const Work& W, bool actuation, real tol) {
   if (NPAIR > 0) contact_rows(E, W);
   FPROF(4);
   // ---- phase 2 (the frames in LDS are dead from here on)
-  if (team_factor(W, L, M, nullptr, 0u, R(0), false, FlipList{nullptr, -1}, false, 0, L))
-    E.warn |= WARN_INERTIA;
-  FPROF(1);
   for (int i = tl; i < NV; i += TEAM) { qas[i] = fs[i]; fc[i] = 0; }
   tsync();
-  team_solve(W, qas, L, nullptr, 0u);
+  if (team_factor(W, L, M, nullptr, 0u, R(0), false, FlipList{nullptr, -1, nullptr, 0}, false, 0, L, qas))
+    E.warn |= WARN_INERTIA;
+  FPROF(1);
+  team_solve(W, qas, L, nullptr, 0u, true);
   FPROF(2);
   if (E.nefc == 0) {
     for (int i = tl; i < NV; i += TEAM) q[i] = qas[i];
@@ -3700,8 +3737,8 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
       const auto A = Mats::local(nullptr, W, MAT_A);
       for (int i = tl; i < NV; i += TEAM) x[i] = E.qfrc_smooth[i] + E.qfrc_constraint[i];
       tsync();
-      team_factor(W, A, M, nullptr, 0u, h, false, FlipList{nullptr, -1}, false, 0, A);
-      team_solve(W, x, A, nullptr, 0u);
+      team_factor(W, A, M, nullptr, 0u, h, false, FlipList{nullptr, -1, nullptr, 0}, false, 0, A, x);
+      team_solve(W, x, A, nullptr, 0u, true);
     } else {
       for (int i = tl; i < NV; i += TEAM) x[i] = E.qacc[i];
       tsync();
