@@ -599,11 +599,13 @@ struct Env {
   // (big scenes, MAT_IN_WS: the inertial frames are recomputed where com_pos
   // needs them instead of being kept -- the fp64 frame must stay below 128 KB)
   real xipos[NBODY*3], ximat[MAT_IN_WS ? 9 : NBODY*9];
-  real xanchor[(NJNT > 0 ? NJNT : 1)*3], xaxis[(NJNT > 0 ? NJNT : 1)*3];
+  // (xanchor ... cvel: tree-local, but kept in LDS words that are idle while the
+  // recursions run -- scratch latency was most of that phase)
+  DMC_SHARED(xanchor, (NJNT > 0 ? NJNT : 1)*3); DMC_SHARED(xaxis, (NJNT > 0 ? NJNT : 1)*3);
   DMC_SHARED(subtree_com, NBODY*3);
   real cinert[NBODY*10];
   DMC_SHARED(cdof, NVX*6);
-  real cdof_dot[NVX*6], cvel[NBODY*6];
+  DMC_SHARED(cdof_dot, NVX*6); DMC_SHARED(cvel, NBODY*6);
   real qM[MAT_REGS], qL[MAT_REGS];
   DMC_SHARED(qfrc_smooth, NVX); DMC_SHARED(qfrc_constraint, NVX);
   DMC_SHARED(qacc_smooth, NVX); DMC_SHARED(qacc, NVX);
@@ -708,7 +710,7 @@ enum { MAT_M = 0, MAT_L = 1, MAT_H = 2, MAT_A = 3 };
 constexpr int TB = 64;                  // largest tree (dofs) a team build takes
 constexpr int TSTR = TB + 1;
 // (and the vectors of the dynamics: one copy per env instead of one per lane in scratch)
-constexpr int TL_VEC = 0, TL_X = TL_VEC + 2*NVX, TL_Q = TL_X + NVX, TL_MA = TL_Q + NVX,
+constexpr int TL_X = 0, TL_Q = TL_X + NVX, TL_MA = TL_Q + NVX,
               TL_MV = TL_MA + NVX, TL_FS = TL_MV + NVX, TL_FC = TL_FS + NVX, TL_QAS = TL_FC + NVX,
               TL_ROW = TL_QAS + NVX, TL_HLO = TL_ROW + (NVX > 4*TB ? NVX : 4*TB),
               TL_QPOS = TL_HLO + NVX, TL_QVEL = TL_QPOS + (NQ > 0 ? NQ : 1), TL_WARM = TL_QVEL + NVX,
@@ -723,7 +725,20 @@ constexpr int NGX_ = NGEOM > 0 ? NGEOM : 1;
 constexpr int TL_GEOM = TL_PHASE, TL_XPOS = TL_GEOM + 12*NGX_, TL_XQUAT = TL_XPOS + 3*NBODY,
               TL_XMAT = TL_XQUAT + 4*NBODY, TL_SCOM = TL_XMAT + 9*NBODY,
               TL_CDOF = TL_SCOM + 3*NBODY, TL_END1 = TL_CDOF + 6*NVX;
-constexpr int TEAM_LDS_WORDS = TEAMED ? (TL_END1 > TL_END2 ? TL_END1 : TL_END2) : 1;
+// While the tree recursions run, the solver's vectors, the row segment, the
+// envelope and the geom mirror are idle: their words hold the recursions' temporaries.
+// (where a model's sizes do not allow it, they get words of their own at the end)
+constexpr int NJX_ = NJNT > 0 ? NJNT : 1;
+constexpr int TL_EXTRA = TL_END1 > TL_END2 ? TL_END1 : TL_END2;
+constexpr bool FIT_G = 6*NVX + 3*NJX_ <= 12*NGX_;        // cdof_dot, xaxis: the geom mirror's words
+constexpr bool FIT_V = 6*NBODY <= TL_FS - TL_X;          // cvel: x, qacc, Ma, Mv
+constexpr bool FIT_R = 3*NJX_ <= TL_QPOS - TL_FC;        // xanchor: fc, qacc_smooth, row segment, envelope
+constexpr int TL_CDOFDOT = FIT_G ? TL_GEOM : TL_EXTRA, TL_XAXIS = TL_CDOFDOT + 6*NVX;
+constexpr int TL_EX1 = FIT_G ? TL_EXTRA : TL_XAXIS + 3*NJX_;
+constexpr int TL_CVEL = FIT_V ? TL_X : TL_EX1, TL_EX2 = FIT_V ? TL_EX1 : TL_EX1 + 6*NBODY;
+constexpr int TL_XANCHOR = FIT_R ? TL_FC : TL_EX2, TL_EX3 = FIT_R ? TL_EX2 : TL_EX2 + 3*NJX_;
+constexpr int TEAM_LDS_WORDS = TEAMED ? TL_EX3 : 1;
+static_assert(!TEAMED || (long long)TEAM_LDS_WORDS*sizeof(real) <= 160*1024, "team LDS beyond a CU's");
 
 template <bool T> struct WsRowT { typedef GlbRow type; };
 template <> struct WsRowT<true> { typedef TeamRow type; };
@@ -3378,6 +3393,8 @@ DEV void team_bind(Env& E, const Work& W) {
   E.qfrc_smooth = W.lds + TL_FS; E.qfrc_constraint = W.lds + TL_FC;
   E.qacc_smooth = W.lds + TL_QAS; E.qacc = W.lds + TL_Q;
   E.qpos = W.lds + TL_QPOS; E.qvel = W.lds + TL_QVEL; E.warm = W.lds + TL_WARM;
+  E.cdof_dot = W.lds + TL_CDOFDOT; E.xaxis = W.lds + TL_XAXIS;
+  E.cvel = W.lds + TL_CVEL; E.xanchor = W.lds + TL_XANCHOR;
   E.rb0 = 1; E.rb1 = NBODY; E.rj0 = 0; E.rj1 = NJNT; E.rd0 = 0; E.rd1 = NV;
 }
 DEV void team_range(Env& E, int t) {
@@ -3726,6 +3743,9 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
     // every vector is shared (LDS): the lanes split the dofs and the joints
     const int tl = tlane();
     forward(E, W, true, tol);
+#ifdef DMC_STEP_PROFILE
+    const long long tp_ = wall_clock64();
+#endif
     bool ba = false;
     for (int i = tl; i < NV; i += TEAM) ba |= bad(E.qacc[i]);
     if (tany(ba)) { E.warn |= WARN_BADQACC; reset_state(E, time); return; }
@@ -3748,6 +3768,9 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
     integrate_pos(E.qpos, E.qvel, h);
     tsync();
     time += h;
+#ifdef DMC_STEP_PROFILE
+    E.prof[6] += (real)(wall_clock64() - tp_);
+#endif
     return;
   }
   if (INTEGRATOR == 0) {
@@ -4292,8 +4315,14 @@ dmc_step(DmcArgs a) {
     for (int i = 0; i < NU; i++) E.ctrl[i] = a.ctrl_store[i*n + e];
   }
   const real tol = R(tolerance_opt > DMC_TOL_FLOOR ? tolerance_opt : DMC_TOL_FLOOR);
+#ifdef DMC_STEP_PROFILE
+  const long long tk_ = wall_clock64();
+#endif
   for (int s = 0; s < a.nsub; s++)
     physics_step(E, W, time, tol, s == 0 && (a.flags & DMC_FLAG_STALE_FIRST));
+#ifdef DMC_STEP_PROFILE
+  E.prof[7] = (real)(wall_clock64() - tk_);      // all substeps
+#endif
   if (a.qacc) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];

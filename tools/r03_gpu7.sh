@@ -11,4 +11,5 @@ import json
 d=json.loads(open('gpurun_out/r03g/bench_soccer_team.json').read().strip().splitlines()[-1])
 print('bench', d['value'], 'env-steps/s', d['ms_per_step'], 'ms/step kernel', d['roofline'].get('kernel_ms_avg'), 'cpu', d['cpu_baseline']['value'], d['cpu_baseline'].get('qpos_rel_err',{}).get('teacher_forced'))
 PY
-timeout -k 10 300 python tools/debug/pitch_profile.py loud --team --solver > $O/pitch_solver_profile_team.txt 2>&1; cat $O/pitch_solver_profile_team.txt | tail -12
+
+timeout -k 10 300 python tools/debug/pitch_bench_profile.py stage > $O/pitch_bench_stage_profile.txt 2>&1; tail -10 $O/pitch_bench_stage_profile.txt

@@ -1,3 +1,3 @@
 #!/bin/bash
 O=gpurun_out/r03h; mkdir -p $O
-timeout -k 10 300 python tools/debug/pitch_profile.py loud --team --solver > $O/pitch_solver_profile_team.txt 2>&1; cat $O/pitch_solver_profile_team.txt | tail -12
+timeout -k 10 300 python tools/debug/pitch_bench_profile.py stage > $O/pitch_bench_stage_profile.txt 2>&1; tail -10 $O/pitch_bench_stage_profile.txt
