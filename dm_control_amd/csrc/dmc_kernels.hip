@@ -1179,6 +1179,18 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hl
   if (flips && coupled) team_cross_flips(H, W, nefc, hlo, first);
   for (int t = 0; t < NDTREE; t++) {
     const int s = dtree_lo[t], e = dtree_hi[t], n = e - s + 1;
+    if (flips && !first && !coupled && L.n >= 0 && xfwd) {
+      // a block that no listed change touches keeps its factor: only the
+      // right-hand side passes through it
+      bool touched = false;
+      for (int f = tl; f < L.n1; f += TEAM) { const int d = (int)L.p1[2*f]; touched |= d >= s && d <= e; }
+      for (int f = tl; f < L.n; f += TEAM) touched |= (int)L.p[4*f + 2] >= s && (int)L.p[4*f + 1] <= e;
+      if (!tany(touched)) {
+        tile_load(T, dst, s, n);
+        tile_forward(T, xfwd + s, n);
+        continue;
+      }
+    }
     tile_load(T, src, s, n);
     if (damping_h != 0) {
       for (int ii = tl; ii < n; ii += TEAM) T[ii*TSTR + ii] += damping_h*R(dof_damping[s + ii]);
@@ -1337,10 +1349,20 @@ DEV void team_take(real* mine, const real* shared) {
 // ---------------------------------------------------------------------------
 // position stage: kinematics, centre-of-mass frame, composite inertia
 // ---------------------------------------------------------------------------
-DEV void kinematics(Env& E) {
+// the world body's frame and velocity (team mode: shared words, written once
+// per pass by lane 0 before the trees' lanes start)
+DEV void world_frames(Env& E) {
   E.xpos[0] = E.xpos[1] = E.xpos[2] = 0;
   E.xquat[0] = 1; E.xquat[1] = E.xquat[2] = E.xquat[3] = 0;
   quat2mat(E.xmat, E.xquat);
+  for (int k = 0; k < 6; k++) E.cvel[k] = 0;
+}
+DEV void kinematics(Env& E) {
+  if (!TEAMED) {
+    E.xpos[0] = E.xpos[1] = E.xpos[2] = 0;
+    E.xquat[0] = 1; E.xquat[1] = E.xquat[2] = E.xquat[3] = 0;
+    quat2mat(E.xmat, E.xquat);
+  }
   DMC_UNROLL
   for (int k = 0; k < 3; k++) E.xipos[k] = 0;
   DMC_UNROLL
@@ -1583,6 +1605,7 @@ DEV void crb_factor(Env& E, const Work& W) {
 // velocity stage: body velocities, passive forces, RNE bias
 // ---------------------------------------------------------------------------
 DEV void com_vel(Env& E) {
+  if (!TEAMED)
   DMC_UNROLL
   for (int k = 0; k < 6; k++) E.cvel[k] = 0;
   DMC_UNROLL
@@ -3464,6 +3487,7 @@ DEV void forward_team(Env& E, const Work& W, bool actuation, real tol) {
   // the rows of M inside the trees' envelope start from zero
   for (int i = 0; i < NV; i++)
     for (int j = dof_treeroot[i] + tl; j <= i; j += TEAM) M.set(tri(i, j), 0);
+  if (tl == 0) world_frames(E);
   tsync();
   if (tl % LANES_PER_GROUP == 0) {
     for (int t = tl/LANES_PER_GROUP; t < NTREE; t += NGROUPS) {
@@ -3890,7 +3914,7 @@ DEV void physics_step(Env& E, const Work& W, real& time, real tol, bool stale = 
 DEV void observe_stage(Env& E, real& time) {
   check_state(E, time);
   if (TEAMED) {                 // the recursions of all trees on lane 0 (frames land in LDS)
-    if (tlane() == 0) { kinematics(E); com_pos(E); com_vel(E); subtree_vel(E); }
+    if (tlane() == 0) { world_frames(E); kinematics(E); com_pos(E); com_vel(E); subtree_vel(E); }
     tsync();
     return;
   }
@@ -4308,6 +4332,7 @@ dmc_step(DmcArgs a) {
       DMC_UNROLL
       for (int i = 0; i < NU; i++) E.ctrl[i] = 0;
     }
+    if (!TEAMED || tlane() == 0)
     DMC_UNROLL
     for (int i = 0; i < NU; i++) a.ctrl_store[i*n + e] = E.ctrl[i];
   } else {
@@ -4323,7 +4348,7 @@ dmc_step(DmcArgs a) {
 #ifdef DMC_STEP_PROFILE
   E.prof[7] = (real)(wall_clock64() - tk_);      // all substeps
 #endif
-  if (a.qacc) {
+  if (a.qacc && (!TEAMED || tlane() == 0)) {
     DMC_UNROLL
     for (int i = 0; i < NV; i++) a.qacc[i*n + e] = E.qacc[i];
   }

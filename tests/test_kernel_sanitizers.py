@@ -246,3 +246,98 @@ def test_several_lanes_per_env_source(name, sanitizer, group, steps, tmp_path):
     seen += 1
   assert seen == steps*nenv
   assert touched or name == 'cartpole'
+
+
+# ---------------------------------------------------------------------------
+# team mode of csrc/dmc_kernels.hip (one wavefront per env, big scenes): one OS
+# thread per lane, a phase boundary (tsync) is a pthread barrier
+# ---------------------------------------------------------------------------
+def _build_team(model, tmp_path, sanitizer, team, ncon_max=64):
+  header = tmp_path/'model.h'
+  text = codegen.generate_header(model, 0, ncon_max=ncon_max, unroll=False)
+  header.write_text(text.replace('static __device__ constexpr',
+                                 'static constexpr'))
+  exe = tmp_path/'harness_team'
+  cmd = ['g++', '-std=c++17', '-w', '-O1', '-g', '-pthread',
+         '-fsanitize=' + sanitizer, '-fno-omit-frame-pointer',
+         '-DDMC_REAL_IS_DOUBLE', '-DDMC_TEAM=%d' % team,
+         '-DDMC_MODEL_HEADER="%s"' % header,
+         '-DDMC_KERNEL_SOURCE="%s"' % KERNEL,
+         '-I', os.path.join(ROOT, 'dm_control_amd', 'csrc'), '-I', SHIM,
+         '-x', 'c++', os.path.join(SHIM, 'harness_team.cpp'), '-o', str(exe)]
+  if 'undefined' in sanitizer:
+    cmd.insert(1, '-fno-sanitize-recover=undefined')
+  subprocess.check_call(cmd)
+  return str(exe)
+
+
+def _team_scene(name):
+  """Scenes of several humanoids and a ball with contacts BETWEEN kinematic
+  trees (the coupled blocks of the Hessian): two walkers pushed into each other
+  with the ball between their feet; four walkers in a tangle."""
+  from dm_control_amd.locomotion.models import soccer
+  rs = np.random.RandomState(3)
+  if name == 'two_walkers_touching':
+    m = compiler.from_xml_string(soccer.build(2, with_ball=True, ball=soccer.REGULATION_BALL))
+  else:
+    m = compiler.from_xml_string(soccer.build(4, with_ball=True, ball=soccer.REGULATION_BALL,
+                                              goal_size=(1.0, 1.6, 1.0)))
+  nw = (m.nq - 7)//63
+  qpos = np.array(m.qpos0, float)
+  for k in range(nw):
+    qpos[63*k + 2] = 0.86 + 0.02*k          # feet in the ground
+    qpos[63*k + 7:63*k + 63] += 0.3*rs.randn(56)
+  if name == 'two_walkers_touching':
+    qpos[63:65] = qpos[0:2] + [0.25, 0.0]
+    qpos[126:129] = [qpos[0] + 0.1, qpos[1], 0.10]
+  else:
+    for k, (x, y) in enumerate([(0, 0), (0.3, 0), (0, 0.35), (0.3, 0.35)]):
+      qpos[63*k:63*k + 2] = [x, y]
+    qpos[252:255] = [0.15, 0.17, 0.45]
+  return m, qpos, 0.5*rs.randn(m.nv)
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize('name,sanitizer,team,steps', [
+    ('two_walkers_touching', 'address,undefined', 8, 3),
+    ('two_walkers_touching', 'thread', 8, 2),
+    ('four_walkers_tangled', 'address,undefined', 8, 2),
+    ('four_walkers_tangled', 'thread', 4, 1)])
+def test_team_build_of_a_scene_with_several_trees(name, sanitizer, team, steps, tmp_path):
+  """csrc/dmc_kernels.hip in team mode (-DDMC_TEAM: the lanes of a wavefront
+  share ONE env -- what `locomotion.soccer` runs) with one thread per lane:
+  shared LDS / workspace words have one writer per phase (ThreadSanitizer),
+  every index is in range (AddressSanitizer), and the trajectory is the
+  oracle's -- with contacts between trees, so the coupled blocks of the Newton
+  Hessian (rows left of a tree's tile) are factored and solved too."""
+  m, qpos, qvel = _team_scene(name)
+  exe = _build_team(m, tmp_path, sanitizer, team)
+  args = [exe, str(steps)] + ['%.17g' % x for x in qpos] + ['%.17g' % x for x in qvel]
+  env = dict(os.environ, ASAN_OPTIONS='detect_leaks=0', TSAN_OPTIONS='halt_on_error=1')
+  out = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, env=env, timeout=1400)
+  assert out.returncode == 0, out.stderr[-3000:]
+  om = oracle.OracleModel(m)
+  d = oracle.OracleData(om)
+  d.qpos[:] = qpos
+  d.qvel[:] = qvel
+  d.step1()
+  seen, coupled = 0, False
+  tree_of_dof = np.asarray(m.body_rootid)[np.asarray(m.dof_bodyid)]
+  for line in out.stdout.splitlines():
+    if not line.startswith('STEP'):
+      continue
+    vals, tail = line.split('|')
+    state = np.array([float(x) for x in vals.split()[2:]])
+    ncon, nefc, iters, warn = [int(x) for x in tail.split()]
+    assert (ncon, nefc) == (d.ncon, d.nefc)
+    J = np.asarray(d.efc_J_matrix())[:d.nefc] if callable(getattr(d, 'efc_J_matrix', None)) else None
+    if J is not None:
+      coupled |= any(len(set(tree_of_dof[np.nonzero(row)[0]])) > 1 for row in J)
+    d.physics_step()
+    assert warn == 0
+    np.testing.assert_allclose(state[:m.nq], d.qpos, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(state[m.nq:], d.qvel, rtol=0, atol=1e-8)
+    seen += 1
+  assert seen == steps
+  assert coupled, 'no constraint row touched two trees: the scene does not test the coupling'
