@@ -362,9 +362,12 @@ def test_known_answer_models_on_device(key, mode):
   raises; asserted below) -- and builds of this kind have twice produced a
   wrong trajectory on the GPU after semantics-preserving source edits
   (tools/spill_hazard/).  It is built here with the explicit
-  override as a canary whose outcome is REPORTED, not asserted: with the sources
-  of round 2 it was exact, with those of round 3 it is wrong again (rel. error
-  1.2 after 150 steps) -- which is the point of refusing it in the product."""
+  override was a canary whose outcome was reported, not asserted: with the
+  sources of round 2 it was exact, mid round 3 it was wrong again (rel. error 1.2
+  after 150 steps), and with the final sources of round 3 the process ABORTED
+  inside the step (profiles/r03_overbudget_canary_abort.txt).  A build that can
+  take the process down is not run on a shared GPU again: what is left of the
+  canary is the assertion that the product refuses the build."""
   model = compiler.from_xml_string(kat_models.GPU_MODELS[key])
   nenv = 32
   if (key, mode) == ('primitives', 'unrolled'):
@@ -372,10 +375,8 @@ def test_known_answer_models_on_device(key, mode):
     assert os.environ.get('DMC_ALLOW_OVERBUDGET') != '1'
     with pytest.raises(RuntimeError, match='spills'):   # the product path refuses it
       build.build_model(model, codegen.TASK_NONE, 'f64', mode='unrolled')
-    with build.allow_overbudget():
-      hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv, mode)
-  else:
-    hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv, mode)
+    return
+  hm, hb = _device_batch(model, codegen.TASK_NONE, 'f64', nenv, mode)
   rs = np.random.RandomState(2)
   qpos = np.tile(model.qpos0, (nenv, 1))
   qvel = 0.2*rs.randn(nenv, model.nv)
@@ -400,11 +401,6 @@ def test_known_answer_models_on_device(key, mode):
       touched |= d.ncon > 0
   q = hb.read(W.FIELD_QPOS).T[:, :model.nq]
   nq = np.array([d.qpos.copy() for d in datas])
-  if (key, mode) == ('primitives', 'unrolled'):
-    print('OBSERVED over-budget unrolled fp64 build of the 20-dof model (canary, refused by '
-          'the product): max rel err vs oracle after 150 steps %.3g'
-          % helpers.rel_err(q, nq).max())
-    return
   assert helpers.rel_err(q, nq).max() <= 1e-6
   assert touched                              # the contact path was exercised
   if key == 'readme_box':
