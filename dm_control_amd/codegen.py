@@ -548,6 +548,19 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   for name, vals in (('tree_body_lo', tb_lo), ('tree_body_hi', tb_hi), ('tree_jnt_lo', tj_lo),
                      ('tree_jnt_hi', tj_hi), ('tree_dof_lo', td_lo), ('tree_dof_hi', td_hi)):
     ti(name, vals or [0])
+  # ... and of actuators (by the dof an actuator's transmission starts at); -1 / -1:
+  # the model's actuators are not grouped by tree (then every tree's lane scans all)
+  ta_lo, ta_hi, grouped = [], [], True
+  first_dof = [int(w_dof[w_adr[i]]) if w_num[i] else -1 for i in range(m.nu)]
+  for t in range(len(td_lo)):
+    acts = [i for i in range(m.nu) if td_lo[t] <= first_dof[i] < td_hi[t]]
+    if acts and acts != list(range(acts[0], acts[-1] + 1)):
+      grouped = False
+    ta_lo.append(acts[0] if acts else 0); ta_hi.append(acts[-1] + 1 if acts else 0)
+  if not grouped or any(d < 0 for d in first_dof):
+    ta_lo, ta_hi = [-1]*len(td_lo), [-1]*len(td_lo)
+  ti('tree_act_lo', ta_lo or [0])
+  ti('tree_act_hi', ta_hi or [0])
   ti('geom_tree', [tree_of_body[int(b)] for b in m.geom_bodyid] or [-1])
   ti('pair_tree1', [tree_of_body[int(m.geom_bodyid[p[0]])] for p in pairs] or [-1])
   ti('pair_tree2', [tree_of_body[int(m.geom_bodyid[p[1]])] for p in pairs] or [-1])

@@ -101,6 +101,10 @@ static_assert(TEAM >= 2 && TEAM <= 64 && (TEAM & (TEAM - 1)) == 0, "team = power
 constexpr int TEAM = 1;
 #endif
 constexpr bool TEAMED = TEAM > 1;
+// the lanes of a team in groups: a group per kinematic tree at a time (its first
+// lane runs the tree's recursions)
+constexpr int NGROUPS = TEAM >= 8 ? 4 : (TEAM >= 2 ? TEAM/2 : 1);
+constexpr int LANES_PER_GROUP = TEAM/NGROUPS;
 
 #if defined(DMC_TEAM) && !defined(DMC_HOST_SHIM)
 DEV int tlane() { return (int)(threadIdx.x & (TEAM - 1)); }
@@ -576,6 +580,8 @@ DEV void copy_env(const Mat& dst, const Mat& src, const Lo& lo, const SLo& slo) 
 #define JNT_HI(E) ((E).rj1)
 #define DOF_LO(E) ((E).rd0)
 #define DOF_HI(E) ((E).rd1)
+#define ACT_LO(E) ((E).ra0)
+#define ACT_HI(E) ((E).ra1)
 #else
 #define DMC_SHARED(name, n) real name[n]
 #define BODY_LO(E) 1
@@ -585,6 +591,8 @@ DEV void copy_env(const Mat& dst, const Mat& src, const Lo& lo, const SLo& slo) 
 #define JNT_HI(E) NJNT
 #define DOF_LO(E) 0
 #define DOF_HI(E) NV
+#define ACT_LO(E) 0
+#define ACT_HI(E) NU
 #endif
 struct Env {
   DMC_SHARED(qpos, NQ > 0 ? NQ : 1); DMC_SHARED(qvel, NVX); DMC_SHARED(warm, NVX);
@@ -593,7 +601,7 @@ struct Env {
   real qpos_lo[NQ > 0 ? NQ : 1], qvel_lo[NVX];   // low words of the fp64 state
 #endif
 #ifdef DMC_TEAM
-  int rb0, rb1, rj0, rj1, rd0, rd1;   // the bodies / joints / dofs this lane's recursions cover
+  int rb0, rb1, rj0, rj1, rd0, rd1, ra0, ra1;   // the bodies / joints / dofs / actuators this lane's recursions cover
 #endif
   DMC_SHARED(xpos, NBODY*3); DMC_SHARED(xquat, NBODY*4); DMC_SHARED(xmat, NBODY*9);
   // (big scenes, MAT_IN_WS: the inertial frames are recomputed where com_pos
@@ -955,11 +963,17 @@ DEV int tile_factor(real* T, int n) {
   }
   return nbad;
 }
-// sum_k A[bi + k] B[bj + k], k in [k0, k1): eight loads of each in flight
+// sum_k A[bi + k] B[bj + k], k in [k0, k1): 32 (then 8) loads of each in flight --
+// the rows live in HBM and a lone wavefront only hides that latency with loads in flight
 template <class Mat>
 DEV real env_dot2(const Mat& A, int bi, int bj, int k0, int k1) {
   real t = 0;
   int k = k0;
+  for (; k + 32 <= k1; k += 32) {
+    real a[32], b[32];
+    _Pragma("unroll") for (int u = 0; u < 32; u++) { a[u] = A.get(bi + k + u); b[u] = A.get(bj + k + u); }
+    _Pragma("unroll") for (int u = 0; u < 32; u++) t += a[u]*b[u];
+  }
   for (; k + 8 <= k1; k += 8) {
     real a[8], b[8];
     _Pragma("unroll") for (int u = 0; u < 8; u++) { a[u] = A.get(bi + k + u); b[u] = A.get(bj + k + u); }
@@ -1539,10 +1553,11 @@ DEV void com_pos(Env& E) {
   }
 }
 
-// team mode: composite inertias and the rows of M of this lane's tree (the rows
-// were cleared by the team beforehand; forward_team() factors M afterwards)
+// team mode: composite inertias of this lane's tree and, per dof, the composite
+// inertia times the dof's axis (6 words, parked in the workspace words of Euler's
+// matrix, which is idle here); crb_rows_team() turns them into the rows of M
 DEV void crb_tree(Env& E, const Work& W) {
-  const auto M = Mats::M(E, W);
+  const auto P = W.mat(MAT_A);
   real crb[NBODY*10];
   for (int i = BODY_LO(E); i < BODY_HI(E); i++)
     for (int k = 0; k < 10; k++) crb[10*i + k] = E.cinert[10*i + k];
@@ -1552,12 +1567,26 @@ DEV void crb_tree(Env& E, const Work& W) {
   for (int i = DOF_LO(E); i < DOF_HI(E); i++) {
     real buf[6];
     mul_inert_vec(buf, crb + 10*dof_bodyid[i], E.cdof + 6*i);
-    M.set(tri(i, i), dot6(E.cdof + 6*i, buf) + R(dof_armature[i]));
-    for (int a = 0; a < dof_anc_len[i]; a++) {
-      const int j = dof_anc[i*MAXCHAIN + a];
-      M.set(tri(i, j), dot6(E.cdof + 6*j, buf));
-    }
+    for (int k = 0; k < 6; k++) P.set(6*i + k, buf[k]);
   }
+}
+// the rows of M (cleared beforehand): the lanes of a tree's group split its dofs,
+// a dof's lane writes the diagonal and the entries of the dof's ancestors
+DEV void crb_rows_team(Env& E, const Work& W) {
+  const auto M = Mats::M(E, W);
+  const auto P = W.mat(MAT_A);
+  const int tl = tlane();
+  for (int t = tl/LANES_PER_GROUP; t < NTREE; t += NGROUPS)
+    for (int i = tree_dof_lo[t] + tl % LANES_PER_GROUP; i < tree_dof_hi[t]; i += LANES_PER_GROUP) {
+      real buf[6];
+      for (int k = 0; k < 6; k++) buf[k] = P.get(6*i + k);
+      M.set(tri(i, i), dot6(E.cdof + 6*i, buf) + R(dof_armature[i]));
+      for (int a = 0; a < dof_anc_len[i]; a++) {
+        const int j = dof_anc[i*MAXCHAIN + a];
+        M.set(tri(i, j), dot6(E.cdof + 6*j, buf));
+      }
+    }
+  tsync();
 }
 
 // composite rigid body algorithm -> packed M, then M = L L^T
@@ -1705,7 +1734,7 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
     // transmission = list of (dof, coefficient): a joint, or the joints a fixed
     // tendon wraps; the point-mass task varies the coefficients per instance
     DMC_UNROLL
-    for (int i = 0; i < NU; i++) {
+    for (int i = ACT_LO(E); i < ACT_HI(E); i++) {
       if (TEAMED) {       // the actuators of this lane's tree (an actuator acts inside one tree)
         const int d = act_wrap_dof[act_wrap_adr[i]];
         if (d < DOF_LO(E) || d >= DOF_HI(E)) continue;
@@ -3397,7 +3426,9 @@ DEV void touch_sensors(Env& E, const Work& W) {
 // -DDMC_STEP_PROFILE (experiments, tools/debug/pitch_profile.py): 100 MHz stamps
 // per stage of forward(), summed per lane into E.prof[0..6], written over the
 // first words of the aux xpos output
-#ifdef DMC_STEP_PROFILE
+#if defined(DMC_STEP_PROFILE) && defined(DMC_TREE_PROFILE)
+#define FPROF(k) do { (void)tf_; } while (0)
+#elif defined(DMC_STEP_PROFILE)
 #define FPROF(k) do { const long long t_ = wall_clock64(); E.prof[k] += (real)(t_ - tf_); tf_ = t_; } while (0)
 #else
 #define FPROF(k) do {} while (0)
@@ -3407,8 +3438,6 @@ DEV void touch_sensors(Env& E, const Work& W) {
 // tree (NGROUPS trees at a time), then limits and contacts with the whole team;
 // phase 2 -- the linear algebra (factor of M, qacc_smooth, warm start, Newton).
 // ---------------------------------------------------------------------------
-constexpr int NGROUPS = TEAM >= 8 ? 4 : (TEAM >= 2 ? TEAM/2 : 1);
-constexpr int LANES_PER_GROUP = TEAM/NGROUPS;
 #ifdef DMC_TEAM
 DEV void team_bind(Env& E, const Work& W) {
   E.xpos = W.lds + TL_XPOS; E.xquat = W.lds + TL_XQUAT; E.xmat = W.lds + TL_XMAT;
@@ -3418,15 +3447,17 @@ DEV void team_bind(Env& E, const Work& W) {
   E.qpos = W.lds + TL_QPOS; E.qvel = W.lds + TL_QVEL; E.warm = W.lds + TL_WARM;
   E.cdof_dot = W.lds + TL_CDOFDOT; E.xaxis = W.lds + TL_XAXIS;
   E.cvel = W.lds + TL_CVEL; E.xanchor = W.lds + TL_XANCHOR;
-  E.rb0 = 1; E.rb1 = NBODY; E.rj0 = 0; E.rj1 = NJNT; E.rd0 = 0; E.rd1 = NV;
+  E.rb0 = 1; E.rb1 = NBODY; E.rj0 = 0; E.rj1 = NJNT; E.rd0 = 0; E.rd1 = NV; E.ra0 = 0; E.ra1 = NU;
 }
 DEV void team_range(Env& E, int t) {
   E.rb0 = tree_body_lo[t]; E.rb1 = tree_body_hi[t];
   E.rj0 = tree_jnt_lo[t]; E.rj1 = tree_jnt_hi[t];
   E.rd0 = tree_dof_lo[t]; E.rd1 = tree_dof_hi[t];
+  // (actuators grouped by tree: the tree's; else all of them, filtered by dof)
+  E.ra0 = tree_act_lo[t] < 0 ? 0 : tree_act_lo[t]; E.ra1 = tree_act_lo[t] < 0 ? NU : tree_act_hi[t];
 }
 DEV void team_range_all(Env& E) {
-  E.rb0 = 1; E.rb1 = NBODY; E.rj0 = 0; E.rj1 = NJNT; E.rd0 = 0; E.rd1 = NV;
+  E.rb0 = 1; E.rb1 = NBODY; E.rj0 = 0; E.rj1 = NJNT; E.rd0 = 0; E.rd1 = NV; E.ra0 = 0; E.ra1 = NU;
 }
 #else
 DEV void team_bind(Env&, const Work&) {}
@@ -3492,15 +3523,27 @@ DEV void forward_team(Env& E, const Work& W, bool actuation, real tol) {
   if (tl % LANES_PER_GROUP == 0) {
     for (int t = tl/LANES_PER_GROUP; t < NTREE; t += NGROUPS) {
       team_range(E, t);
+#ifdef DMC_TREE_PROFILE      // (experiments: the recursions' shares, in the slots of FPROF 0 1 2 3 4)
+      long long tq_ = wall_clock64(), tn_;
+#define TPROF(k) do { tn_ = wall_clock64(); E.prof[k] += (real)(tn_ - tq_); tq_ = tn_; } while (0)
+#else
+#define TPROF(k) do {} while (0)
+#endif
       kinematics(E);
+      TPROF(0);
       com_pos(E);
+      TPROF(1);
       com_vel(E);
+      TPROF(2);
       crb_tree(E, W);
+      TPROF(3);
       smooth_forces(E, W, actuation);
+      TPROF(4);
     }
     team_range_all(E);
   }
   tsync();
+  crb_rows_team(E, W);
   FPROF(0);
   E.ncon = 0; E.nefc = 0; E.iters = 0; E.nmerged = 0;
   limit_rows_team(E, W);
@@ -4366,7 +4409,7 @@ dmc_step(DmcArgs a) {
   for (int k = 0; k < 8 && k < NOBS; k++) a.obs[(long long)e*a.obs_se + k] = E.prof[k];
 #endif
 #ifdef DMC_STEP_PROFILE
-  if (a.xpos) for (int k = 0; k < 8; k++) a.xpos[(long long)k*n + e] = E.prof[k];
+  if (a.xpos && tlane() == 0) for (int k = 0; k < 8; k++) a.xpos[(long long)k*n + e] = E.prof[k];
 #endif
   store_env(E, a, e, time);
 }

@@ -1,11 +1,12 @@
 """Per-pitch solver / stage times of the team build on the states bench.py visits:
 `soccer.load(2)` with 1024 pitches and U(-1,1) actions.
-usage: pitch_bench_profile.py solver|stage [--build-only]   (sets $DMC_EXTRA_FLAGS itself)"""
+usage: pitch_bench_profile.py solver|stage|tree [--build-only]   (sets $DMC_EXTRA_FLAGS itself)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 WHAT = sys.argv[1]
-os.environ['DMC_EXTRA_FLAGS'] = '-DDMC_SOLVER_PROFILE=1' if WHAT == 'solver' else '-DDMC_STEP_PROFILE=1'
+os.environ['DMC_EXTRA_FLAGS'] = {'solver': '-DDMC_SOLVER_PROFILE=1', 'stage': '-DDMC_STEP_PROFILE=1',
+                                 'tree': '-DDMC_STEP_PROFILE=1 -DDMC_TREE_PROFILE=1'}[WHAT]
 import numpy as np
 from dm_control_amd.locomotion import soccer
 from dm_control_amd import wrapper as W
@@ -41,6 +42,8 @@ if WHAT == 'solver':
 else:
   prof = hb.read(W.FIELD_XPOS)[:8].astype(np.float64)/100.0
   names = ['tree recursions', 'factor M', 'qacc_smooth', 'limit rows', 'contact rows', 'warm start+Newton']
+  if WHAT == 'tree':      # lane 0 = the first tree's lane: the shares of its recursions
+    names = ['kinematics', 'com_pos', 'com_vel', 'crb + rows of M', 'RNE + actuation', '-']
   for k in range(6):
     print('  %-20s mean %9.1f us  max %9.1f us' % (names[k], prof[k].mean(), prof[k].max()))
   tot = prof[:6].sum(axis=0)
