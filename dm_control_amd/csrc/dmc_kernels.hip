@@ -872,14 +872,16 @@ DEV int tpopc(unsigned long long m) { return __builtin_popcountll(m); }
 // first k >= lo that lane `tl` owns (k = tl mod TEAM)
 DEV int towned_from(int lo, int tl) { return lo + ((tl - lo) & (TEAM - 1)); }
 
-// tile <- A[s .. s+n-1][s .. row]; 32 rows in flight
+// tile <- A[s .. s+n-1][s .. row]; all rows of the tile in flight at once (the
+// rows live in HBM; a lone wavefront hides that latency only with loads in flight)
 template <class Mat>
 DEV void tile_load(real* T, const Mat& A, int s, int n) {
   const int tl = tlane();
-  for (int i0 = 0; i0 < n; i0 += 32) {
-    real a[32][KPL];
+  constexpr int RB = KPL == 1 ? TB : 16;        // rows per group
+  for (int i0 = 0; i0 < n; i0 += RB) {
+    real a[RB][KPL];
     _Pragma("unroll")
-    for (int u = 0; u < 32; u++) {
+    for (int u = 0; u < RB; u++) {
       const int ii = i0 + u;
       _Pragma("unroll")
       for (int m = 0; m < KPL; m++) {
@@ -888,7 +890,7 @@ DEV void tile_load(real* T, const Mat& A, int s, int n) {
       }
     }
     _Pragma("unroll")
-    for (int u = 0; u < 32; u++) {
+    for (int u = 0; u < RB; u++) {
       const int ii = i0 + u;
       _Pragma("unroll")
       for (int m = 0; m < KPL; m++) {
@@ -1685,6 +1687,57 @@ DEV real wrap_coef(const EnvT& E, int w) {
 }
 
 // qfrc_smooth = passive - bias + actuator ; qacc_smooth = M^-1 qfrc_smooth
+// passive joint forces (springs, dampers) of the joints j0, j0 + js, ... < j1 and
+// the dofs d0, d0 + ds, ... < d1 (team mode: strided over the lanes)
+DEV void passive_forces(Env& E, int j0, int j1, int js, int d0, int d1, int ds) {
+  if (DISABLEFLAGS & DSBL_PASSIVE) return;
+  DMC_UNROLL
+  for (int j = j0; j < j1; j += js)
+    if (jnt_stiffness[j] != 0 &&
+        (jnt_type[j] == JNT_SLIDE || jnt_type[j] == JNT_HINGE)) {
+      const int qa = jnt_qposadr[j];
+      E.qfrc_smooth[jnt_dofadr[j]] -=
+          R(jnt_stiffness[j])*(E.qpos[qa] - R(qpos_spring[qa]));
+    }
+  if (TEAMED) tsync();       // (a joint's lane and its dof's lane differ)
+  DMC_UNROLL
+  for (int i = d0; i < d1; i += ds)
+    E.qfrc_smooth[i] -= R(dof_damping[i])*E.qvel[i];
+}
+// actuator forces of the actuators a0, a0 + as, ... < a1.
+// transmission = list of (dof, coefficient): a joint, or the joints a fixed
+// tendon wraps; the point-mass task varies the coefficients per instance
+DEV void actuator_forces(Env& E, int a0, int a1, int as) {
+  if (DISABLEFLAGS & DSBL_ACTUATION) return;
+  DMC_UNROLL
+  for (int i = a0; i < a1; i += as) {
+    const real gear = R(actuator_gear[i]);
+    real c = E.ctrl[i];
+    if (actuator_ctrllimited[i] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
+      c = clampr(c, R(actuator_ctrlrange[2*i]), R(actuator_ctrlrange[2*i + 1]));
+    real force = R(actuator_gainprm[3*i])*c;
+    if (actuator_biastype[i] == 1) {
+      real length = 0, velocity = 0;
+      DMC_UNROLL
+      for (int k = 0; k < act_wrap_num[i]; k++) {
+        const int w = act_wrap_adr[i] + k;
+        const real coef = wrap_coef(E, w);
+        length += coef*E.qpos[act_wrap_qadr[w]];
+        velocity += coef*E.qvel[act_wrap_dof[w]];
+      }
+      force += R(actuator_biasprm[3*i]) + R(actuator_biasprm[3*i + 1])*gear*length +
+               R(actuator_biasprm[3*i + 2])*gear*velocity;
+    }
+    if (actuator_forcelimited[i])
+      force = clampr(force, R(actuator_forcerange[2*i]), R(actuator_forcerange[2*i + 1]));
+    DMC_UNROLL
+    for (int k = 0; k < act_wrap_num[i]; k++) {
+      const int w = act_wrap_adr[i] + k;
+      if (TEAMED) tatomic_add(E.qfrc_smooth + act_wrap_dof[w], gear*wrap_coef(E, w)*force);
+      else E.qfrc_smooth[act_wrap_dof[w]] += gear*wrap_coef(E, w)*force;
+    }
+  }
+}
 DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
   real cacc[NBODY*6], cfrc[NBODY*6];
   DMC_UNROLL
@@ -1717,55 +1770,10 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
   DMC_UNROLL
   for (int i = DOF_LO(E); i < DOF_HI(E); i++)
     E.qfrc_smooth[i] = -dot6(E.cdof + 6*i, cfrc + 6*dof_bodyid[i]);
-  if (!(DISABLEFLAGS & DSBL_PASSIVE)) {
-    DMC_UNROLL
-    for (int j = JNT_LO(E); j < JNT_HI(E); j++)
-      if (jnt_stiffness[j] != 0 &&
-          (jnt_type[j] == JNT_SLIDE || jnt_type[j] == JNT_HINGE)) {
-        const int qa = jnt_qposadr[j];
-        E.qfrc_smooth[jnt_dofadr[j]] -=
-            R(jnt_stiffness[j])*(E.qpos[qa] - R(qpos_spring[qa]));
-      }
-    DMC_UNROLL
-    for (int i = DOF_LO(E); i < DOF_HI(E); i++)
-      E.qfrc_smooth[i] -= R(dof_damping[i])*E.qvel[i];
-  }
-  if (actuation && !(DISABLEFLAGS & DSBL_ACTUATION)) {
-    // transmission = list of (dof, coefficient): a joint, or the joints a fixed
-    // tendon wraps; the point-mass task varies the coefficients per instance
-    DMC_UNROLL
-    for (int i = ACT_LO(E); i < ACT_HI(E); i++) {
-      if (TEAMED) {       // the actuators of this lane's tree (an actuator acts inside one tree)
-        const int d = act_wrap_dof[act_wrap_adr[i]];
-        if (d < DOF_LO(E) || d >= DOF_HI(E)) continue;
-      }
-      const real gear = R(actuator_gear[i]);
-      real c = E.ctrl[i];
-      if (actuator_ctrllimited[i] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
-        c = clampr(c, R(actuator_ctrlrange[2*i]), R(actuator_ctrlrange[2*i + 1]));
-      real force = R(actuator_gainprm[3*i])*c;
-      if (actuator_biastype[i] == 1) {
-        real length = 0, velocity = 0;
-        DMC_UNROLL
-        for (int k = 0; k < act_wrap_num[i]; k++) {
-          const int w = act_wrap_adr[i] + k;
-          const real coef = wrap_coef(E, w);
-          length += coef*E.qpos[act_wrap_qadr[w]];
-          velocity += coef*E.qvel[act_wrap_dof[w]];
-        }
-        force += R(actuator_biasprm[3*i]) + R(actuator_biasprm[3*i + 1])*gear*length +
-                 R(actuator_biasprm[3*i + 2])*gear*velocity;
-      }
-      if (actuator_forcelimited[i])
-        force = clampr(force, R(actuator_forcerange[2*i]), R(actuator_forcerange[2*i + 1]));
-      DMC_UNROLL
-      for (int k = 0; k < act_wrap_num[i]; k++) {
-        const int w = act_wrap_adr[i] + k;
-        E.qfrc_smooth[act_wrap_dof[w]] += gear*wrap_coef(E, w)*force;
-      }
-    }
-  }
-  if (TEAMED) return;        // (forward_team() solves for qacc_smooth once M is factored)
+  if (TEAMED) return;        // (forward_team(): passive and actuator forces by the whole team,
+                             //  qacc_smooth once M is factored)
+  passive_forces(E, JNT_LO(E), JNT_HI(E), 1, DOF_LO(E), DOF_HI(E), 1);
+  if (actuation) actuator_forces(E, ACT_LO(E), ACT_HI(E), 1);
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qacc_smooth[i] = E.qfrc_smooth[i];
   if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
@@ -3544,6 +3552,10 @@ DEV void forward_team(Env& E, const Work& W, bool actuation, real tol) {
   }
   tsync();
   crb_rows_team(E, W);
+  passive_forces(E, tl, NJNT, TEAM, tl, NV, TEAM);
+  tsync();
+  if (actuation) actuator_forces(E, tl, NU, TEAM);
+  tsync();
   FPROF(0);
   E.ncon = 0; E.nefc = 0; E.iters = 0; E.nmerged = 0;
   limit_rows_team(E, W);
