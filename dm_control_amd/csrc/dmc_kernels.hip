@@ -875,7 +875,7 @@ DEV int towned_from(int lo, int tl) { return lo + ((tl - lo) & (TEAM - 1)); }
 // tile <- A[s .. s+n-1][s .. row]; all rows of the tile in flight at once (the
 // rows live in HBM; a lone wavefront hides that latency only with loads in flight)
 template <class Mat>
-DEV void tile_load(real* T, const Mat& A, int s, int n) {
+static __device__ __noinline__ void tile_load(real* T, const Mat& A, int s, int n) {   // (one copy: many call sites)
   const int tl = tlane();
   constexpr int RB = KPL == 1 ? TB : 16;        // rows per group
   for (int i0 = 0; i0 < n; i0 += RB) {
