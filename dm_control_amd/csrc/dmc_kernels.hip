@@ -872,12 +872,12 @@ DEV int tpopc(unsigned long long m) { return __builtin_popcountll(m); }
 // first k >= lo that lane `tl` owns (k = tl mod TEAM)
 DEV int towned_from(int lo, int tl) { return lo + ((tl - lo) & (TEAM - 1)); }
 
-// tile <- A[s .. s+n-1][s .. row]; all rows of the tile in flight at once (the
-// rows live in HBM; a lone wavefront hides that latency only with loads in flight)
+// tile <- A[s .. s+n-1][s .. row]; 32 rows in flight (the rows live in HBM; a lone
+// wavefront hides that latency only with loads in flight)
 template <class Mat>
-static __device__ __noinline__ void tile_load(real* T, const Mat& A, int s, int n) {   // (one copy: many call sites)
+DEV void tile_load(real* T, const Mat& A, int s, int n) {
   const int tl = tlane();
-  constexpr int RB = KPL == 1 ? TB : 16;        // rows per group
+  constexpr int RB = KPL == 1 ? 32 : 16;        // rows per group (64 at once measured slower)
   for (int i0 = 0; i0 < n; i0 += RB) {
     real a[RB][KPL];
     _Pragma("unroll")
@@ -4307,6 +4307,21 @@ constexpr bool OBS_STAGE_FITS = !TEAMED && LDS_WORDS >= LANES*(NOBS > 0 ? NOBS :
 DEV void store_outputs(Env& E, const DmcArgs& a, int e, bool accumulate,
                        real* lds_base) {
   const long long n = a.nenv;
+  if (TEAMED && TASK == TASK_NONE && NSENSOR == 0 && NTOUCH == 0) {
+    // no task: the observation is the (shared) state, every lane copies its share
+    tsync();
+    for (int k = tlane(); k < NQ; k += TEAM)
+      a.obs[(long long)k*a.obs_sk + (long long)e*a.obs_se] = E.qpos[k];
+    for (int k = tlane(); k < NV; k += TEAM)
+      a.obs[(long long)(NQ + k)*a.obs_sk + (long long)e*a.obs_se] = E.qvel[k];
+    if (tlane() == 0) {
+      a.reward[e] = 0;
+      if (a.xpos) for (int i = 0; i < NBODY*3; i++) a.xpos[i*n + e] = E.xpos[i];
+      if (a.xmat) for (int i = 0; i < NBODY*9; i++) a.xmat[i*n + e] = E.xmat[i];
+      a.stats[e] = E.ncon; a.stats[n + e] = E.nefc + E.nmerged; a.stats[2*n + e] = E.iters;
+    }
+    return;
+  }
   real obs[NOBS > 0 ? NOBS : 1];
   const real rew = task_outputs(E, a, obs);
   if (TEAMED && tlane() != 0) return;
@@ -4375,7 +4390,21 @@ dmc_step(DmcArgs a) {
       : Work{lds_rows + threadIdx.x, a.ws + e, n};
   team_bind(E, W);
   load_env(E, a, e, time);
-  if (a.flags & 1) {
+  if (TEAMED) {
+    // (a lane applies the actuators i = lane mod TEAM: it fetches those controls)
+    const int tl = tlane();
+    bool bc = false;
+    for (int i = tl; i < NU; i += TEAM) {
+      E.ctrl[i] = (a.flags & 1) ? a.ctrl[i*a.ctrl_sk + (long long)e*a.ctrl_se] : a.ctrl_store[i*n + e];
+      bc |= bad(E.ctrl[i]);
+    }
+    if ((a.flags & 1) && tany(bc)) {
+      E.warn |= WARN_BADCTRL;
+      for (int i = tl; i < NU; i += TEAM) E.ctrl[i] = 0;
+    }
+    if (a.flags & 1)
+      for (int i = tl; i < NU; i += TEAM) a.ctrl_store[i*n + e] = E.ctrl[i];
+  } else if (a.flags & 1) {
     bool bc = false;
     DMC_UNROLL
     for (int i = 0; i < NU; i++) {
