@@ -1772,8 +1772,52 @@ DEV void smooth_forces(Env& E, const Work& W, bool actuation) {
     E.qfrc_smooth[i] = -dot6(E.cdof + 6*i, cfrc + 6*dof_bodyid[i]);
   if (TEAMED) return;        // (forward_team(): passive and actuator forces by the whole team,
                              //  qacc_smooth once M is factored)
-  passive_forces(E, JNT_LO(E), JNT_HI(E), 1, DOF_LO(E), DOF_HI(E), 1);
-  if (actuation) actuator_forces(E, ACT_LO(E), ACT_HI(E), 1);
+  // (one env per lane: the loops stay inline here -- through the helpers above the
+  // generic fp64 cheetah build spilled 437 VGPRs instead of 12)
+  if (!(DISABLEFLAGS & DSBL_PASSIVE)) {
+    DMC_UNROLL
+    for (int j = JNT_LO(E); j < JNT_HI(E); j++)
+      if (jnt_stiffness[j] != 0 &&
+          (jnt_type[j] == JNT_SLIDE || jnt_type[j] == JNT_HINGE)) {
+        const int qa = jnt_qposadr[j];
+        E.qfrc_smooth[jnt_dofadr[j]] -=
+            R(jnt_stiffness[j])*(E.qpos[qa] - R(qpos_spring[qa]));
+      }
+    DMC_UNROLL
+    for (int i = DOF_LO(E); i < DOF_HI(E); i++)
+      E.qfrc_smooth[i] -= R(dof_damping[i])*E.qvel[i];
+  }
+  if (actuation && !(DISABLEFLAGS & DSBL_ACTUATION)) {
+    // transmission = list of (dof, coefficient): a joint, or the joints a fixed
+    // tendon wraps; the point-mass task varies the coefficients per instance
+    DMC_UNROLL
+    for (int i = ACT_LO(E); i < ACT_HI(E); i++) {
+      const real gear = R(actuator_gear[i]);
+      real c = E.ctrl[i];
+      if (actuator_ctrllimited[i] && !(DISABLEFLAGS & DSBL_CLAMPCTRL))
+        c = clampr(c, R(actuator_ctrlrange[2*i]), R(actuator_ctrlrange[2*i + 1]));
+      real force = R(actuator_gainprm[3*i])*c;
+      if (actuator_biastype[i] == 1) {
+        real length = 0, velocity = 0;
+        DMC_UNROLL
+        for (int k = 0; k < act_wrap_num[i]; k++) {
+          const int w = act_wrap_adr[i] + k;
+          const real coef = wrap_coef(E, w);
+          length += coef*E.qpos[act_wrap_qadr[w]];
+          velocity += coef*E.qvel[act_wrap_dof[w]];
+        }
+        force += R(actuator_biasprm[3*i]) + R(actuator_biasprm[3*i + 1])*gear*length +
+                 R(actuator_biasprm[3*i + 2])*gear*velocity;
+      }
+      if (actuator_forcelimited[i])
+        force = clampr(force, R(actuator_forcerange[2*i]), R(actuator_forcerange[2*i + 1]));
+      DMC_UNROLL
+      for (int k = 0; k < act_wrap_num[i]; k++) {
+        const int w = act_wrap_adr[i] + k;
+        E.qfrc_smooth[act_wrap_dof[w]] += gear*wrap_coef(E, w)*force;
+      }
+    }
+  }
   DMC_UNROLL
   for (int i = 0; i < NV; i++) E.qacc_smooth[i] = E.qfrc_smooth[i];
   if (MAT_IN_WS) chol_solve_env(E.qacc_smooth, Mats::L(E, W), LoTree{});
