@@ -1014,6 +1014,78 @@ DEV void team_coupled_tile(real* T, const Mat& F, const int* hlo, int s, int e) 
   }
   tsync();
 }
+// The same two steps for a whole wavefront per env (TEAM = TB: one row of the
+// tree per lane), without walking HBM rows: for every earlier tree the coupled
+// rows reach, that tree's factor tile is staged in LDS, each coupled row takes
+// its right-hand side from H into registers, is solved against the tile there
+// (x L^T = h, straight-line code) and stored as its part of F; what the rows take
+// out of the tree's own tile, G[i][c] = sum_j x_i[j] x_c[j], is summed in
+// over the earlier trees (the other row's x by lane broadcast) in the words of F
+// that the tree's tile will overwrite.  team_factor() subtracts it once the tile
+// is in LDS.
+template <class Mat>
+DEV void team_coupled_rows(real* T, const Mat& F, const Mat& H, const int* hlo, int tu) {
+  const int s = dtree_lo[tu], e = dtree_hi[tu];
+  const int tl = tlane(), i = s + tl;
+  const bool mine = i <= e && hlo[i <= e ? i : e] < s;
+  const int li = mine ? hlo[i] : s;
+  const unsigned long long cmask = tballot(mine);
+  const int lmin = tmin(li);
+  const int bi = tri(i <= e ? i : e, 0);
+  bool first_tile = true;
+  for (int tp = 0; tp < tu; tp++) {
+    const int sp = dtree_lo[tp], ep = dtree_hi[tp], np = ep - sp + 1;
+    if (ep < lmin) continue;
+    tile_load(T, F, sp, np);
+    real x[TB];
+    _Pragma("unroll")
+    for (int j = 0; j < TB; j++)
+      x[j] = (mine && j < np && sp + j >= li) ? H.get(bi + sp + j) : R(0);
+    _Pragma("unroll")
+    for (int j = 0; j < TB; j++)
+      if (j < np) {
+        real a = x[j];
+        _Pragma("unroll")
+        for (int k = 0; k < j; k++) a -= x[k]*T[j*TSTR + k];
+        x[j] = a*T[j*TSTR + j];
+      }
+    _Pragma("unroll")
+    for (int j = 0; j < TB; j++)
+      if (mine && j < np && sp + j >= li) F.set(bi + sp + j, x[j]);
+    // G[il][c] += x_il . x_c: lane c has its own x, row il's comes by broadcast; the
+    // sum is kept in F's words of the tree's tile (the broadcasts hide the load)
+    unsigned long long m = cmask;
+    while (m) {
+      const int il = tfirst_bit(m);
+      m &= m - 1;
+      const int at = tri(s + il, s + tl);
+      const bool keep = tl <= il;
+      const real g = (keep && !first_tile) ? F.get(at) : R(0);
+      real acc = 0;
+      _Pragma("unroll") for (int j = 0; j < TB; j++) acc += x[j]*tget(x[j], il);
+      if (keep) F.set(at, g + acc);
+    }
+    first_tile = false;
+    tsync();                      // (the tile is reloaded in the next round)
+  }
+}
+// ... and the subtraction, with the tree's tile in LDS
+template <class Mat>
+DEV void team_coupled_take(real* T, const Mat& F, const int* hlo, int s, int e) {
+  const int tl = tlane(), i = s + tl;
+  if (i <= e && hlo[i] < s)
+    for (int c0 = 0; c0 <= tl; c0 += 16) {         // sixteen loads in flight
+      real g[16];
+      _Pragma("unroll")
+      for (int u = 0; u < 16; u++) {
+        const int c = c0 + u;
+        g[u] = (c <= tl && hlo[s + (c <= tl ? c : 0)] < s) ? F.get(tri(i, s + c)) : R(0);
+      }
+      _Pragma("unroll")
+      for (int u = 0; u < 16; u++) if (c0 + u <= tl) T[tl*TSTR + c0 + u] -= g[u];
+    }
+  tsync();
+}
 // One pending change of the Hessian: row `r` (dofs lo..hi) enters or leaves with
 // weight w = +-D; a one-dof row (joint limit) carries w = +-D J^2 and is one
 // diagonal entry.  Pass A of the solver lists them in LDS (in row order).
@@ -1207,6 +1279,13 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hl
         continue;
       }
     }
+    const bool coupled_here = flips && ((coupled >> t) & 1u);
+    // (a chain -- this tree coupled to one that is itself coupled further left -- is
+    // left to the rows-in-HBM path: the staged solve assumes block-diagonal earlier factors)
+    bool staged = coupled_here && TEAM == TB;
+    if (staged)
+      for (int tp = 0; tp < t; tp++) staged = staged && !((coupled >> tp) & 1u);
+    if (staged) team_coupled_rows(T, dst, H, hlo, t);
     tile_load(T, src, s, n);
     if (damping_h != 0) {
       for (int ii = tl; ii < n; ii += TEAM) T[ii*TSTR + ii] += damping_h*R(dof_damping[s + ii]);
@@ -1216,9 +1295,12 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hl
       const bool changed = L.n >= 0 ? team_tile_flips_listed(T, W, L, s, e)
                                     : team_tile_flips_scanned(T, W, nefc, s, e);
       if (changed || first) tile_store(H, T, s, n);
-      if ((coupled >> t) & 1u) {
-        team_coupled_left(dst, H, hlo, s, e);
-        team_coupled_tile(T, dst, hlo, s, e);
+      if (coupled_here) {
+        if (staged) team_coupled_take(T, dst, hlo, s, e);
+        else {                       // (a chain, or fewer lanes than rows: the rows are walked in HBM)
+          team_coupled_left(dst, H, hlo, s, e);
+          team_coupled_tile(T, dst, hlo, s, e);
+        }
       }
     }
     nbad += tile_factor(T, n);
@@ -3268,8 +3350,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
     tsync();
-    if (iter == 0) team_factor(W, F, M, henv, coupled, R(0), true, flips, true, nefc, H, search);
-    else team_factor(W, F, H, henv, coupled, R(0), true, flips, false, nefc, H, search);
+    team_factor(W, F, iter == 0 ? M : H, henv, coupled, R(0), true, flips, iter == 0, nefc, H, search);
     SPROF(1);
     team_solve(W, search, F, henv, coupled, true);
     SPROF(2);
