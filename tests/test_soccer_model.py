@@ -393,6 +393,42 @@ def test_two_by_two_pitch_on_device_matches_oracle(quiet, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('team_size', [1, 3])
+def test_other_team_sizes_on_the_team_build(team_size):
+  """1v1 (two trees + ball, nv 130) and 3v3 (six trees + ball, nv 378, more
+  trees than lane groups) through `soccer.load` on the one-wavefront-per-pitch
+  build: fp64 per step against the oracle from standing / sunk-in poses, then the
+  environment plays a few control steps without warnings."""
+  from dm_control_amd.locomotion import soccer as soccer_env
+  from dm_control_amd import wrapper as W
+  nenv = 3
+  env = soccer_env.load(team_size, random_state=5,
+                        environment_kwargs={'batch_size': nenv, 'precision': 'f64'})
+  m = env.physics.model
+  nw = 2*team_size
+  assert (m.nq, m.nv) == (63*nw + 7, 62*nw + 6)
+  assert 'team mode' in env.physics.kernel_shape
+  rs = np.random.RandomState(11)
+  qpos = np.tile(m.qpos0, (nenv, 1))
+  qvel = 0.2*rs.randn(nenv, m.nv)
+  for e in range(nenv):
+    for k in range(nw):
+      qpos[e, 63*k + 7:63*k + 63] += 0.15*rs.randn(56)
+      qpos[e, 63*k + 2] = rs.uniform(0.84, 0.92)
+    qpos[e, 63*nw:63*nw + 2] = qpos[e, 0:2] + rs.uniform(-0.2, 0.2, 2)   # the ball at player 0's feet
+    qpos[e, 63*nw + 2] = 0.115
+  e, rows = _teacher_forced(m, env.physics.batch, qpos, qvel, 3, np.random.RandomState(2), W)
+  print('OBSERVED %dv%d pitch f64 team: per-step max %.2e; ncon up to %d, %d rows in all'
+        % (team_size, team_size, e.max(), _teacher_forced.max_ncon, rows))
+  assert _teacher_forced.max_ncon >= 2*nw and e.max() <= 1e-9, e.max()
+  env.reset()
+  for _ in range(4):
+    ts = env.step([rs.uniform(-1, 1, (nenv, 56)) for _ in range(nw)])
+  assert len(ts.reward) == nw and not np.asarray(env.physics.data.warning_mask).any()
+  env.physics.free()
+
+
+@pytest.mark.gpu
 def test_soccer_environment_plays():
   """`locomotion.soccer.load(2)` end to end on the device: 48 pitches, random
   actions for 40 control steps (200 physics steps): no warning bits, finite
