@@ -573,6 +573,24 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
     if keys[i] == keys[i + 1] and keys[i][0] is not None:
       run[i] = run[i + 1] + 1
   ti('pair_run', run or [1])
+  # the list as runs: (first pair, length, keyed) -- keyed runs can be skipped by one
+  # bounding test; the pairs in between (inside a tree, world against world) form
+  # runs of their own.  Team builds test the runs one per lane before they walk them.
+  run_first, run_len, run_keyed, p = [], [], [], 0
+  while p < len(pairs):
+    if keys[p][0] is not None:
+      n = run[p]
+      run_first.append(p); run_len.append(n); run_keyed.append(1)
+    else:
+      n = 1
+      while p + n < len(pairs) and keys[p + n][0] is None:
+        n += 1
+      run_first.append(p); run_len.append(n); run_keyed.append(0)
+    p += n
+  ci('NRUN', len(run_first))
+  ti('run_first', run_first or [0])
+  ti('run_len', run_len or [0])
+  ti('run_keyed', run_keyed or [0])
   # the world geom of a world-vs-tree pair (-1: none): its bound against the tree's
   ti('pair_wgeom', [k[0][1] if k[0] is not None and k[0][0] == 'wt' else -1 for k in keys] or [-1])
   ti('pair_b1', [int(m.geom_bodyid[p[0]]) for p in pairs])

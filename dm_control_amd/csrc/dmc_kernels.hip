@@ -102,7 +102,9 @@ constexpr int TEAM = 1;
 #endif
 constexpr bool TEAMED = TEAM > 1;
 // the lanes of a team in groups: a group per kinematic tree at a time (its first
-// lane runs the tree's recursions)
+// lane runs the tree's recursions).  Group g = the lanes g, g + NGROUPS, ...: the
+// first lanes of the groups are neighbours, so what they keep in scratch (dword
+// interleaved over the lanes of a wavefront) shares memory sectors.
 constexpr int NGROUPS = TEAM >= 8 ? 4 : (TEAM >= 2 ? TEAM/2 : 1);
 constexpr int LANES_PER_GROUP = TEAM/NGROUPS;
 
@@ -1660,8 +1662,8 @@ DEV void crb_rows_team(Env& E, const Work& W) {
   const auto M = Mats::M(E, W);
   const auto P = W.mat(MAT_A);
   const int tl = tlane();
-  for (int t = tl/LANES_PER_GROUP; t < NTREE; t += NGROUPS)
-    for (int i = tree_dof_lo[t] + tl % LANES_PER_GROUP; i < tree_dof_hi[t]; i += LANES_PER_GROUP) {
+  for (int t = tl % NGROUPS; t < NTREE; t += NGROUPS)
+    for (int i = tree_dof_lo[t] + tl/NGROUPS; i < tree_dof_hi[t]; i += LANES_PER_GROUP) {
       real buf[6];
       for (int k = 0; k < 6; k++) buf[k] = P.get(6*i + k);
       M.set(tri(i, i), dot6(E.cdof + 6*i, buf) + R(dof_armature[i]));
@@ -2660,25 +2662,39 @@ DEV void detect_contacts_team(Env& E, const Work& W) {
     const real reach = trad[t] + R(geom_rbound[wg]) + R(pair_margin[p]);
     return dot3(dif, dif) > reach*reach;
   };
-  int p0 = 0;
-  while (p0 < NPAIR) {
-    if (NTREE > 1 && pair_margin[p0] == 0 && far_apart(p0)) { p0 += pair_run[p0]; continue; }
-    const int p = p0 + tl;
-    RawCon rc[4];
-    int mask = 0;
-    if (p < NPAIR && !(NTREE > 1 && far_apart(p))) mask = collide_pair(G, p, rc);
-    int cnt = 0;
-    for (int c = 0; c < 4; c++) cnt += (mask >> c) & 1;
-    int total;
-    int k = E.ncon + tscan(cnt, total);
-    for (int c = 0; c < 4; c++) {
-      if (!((mask >> c) & 1)) continue;
-      if (k < NCON_MAX) write_contact(W.gcon(k), p, rc[c]);
-      k++;
+  // the runs of the pair list (all pairs between the same two trees, or a world geom
+  // and a tree) are tested one per lane; the survivors are walked in chunks of TEAM pairs
+  for (int r0 = 0; r0 < NRUN; r0 += TEAM) {
+    const int r = r0 + tl;
+    bool walk = false;
+    if (r < NRUN) {
+      const int pf = run_first[r];
+      walk = !(run_keyed[r] && NTREE > 1 && pair_margin[pf] == 0 && far_apart(pf));
     }
-    if (E.ncon + total > NCON_MAX) { E.warn |= WARN_CONTACTFULL; E.ncon = NCON_MAX; }
-    else E.ncon += total;
-    p0 += TEAM;
+    unsigned long long live = tballot(walk);
+    while (live) {
+      const int rr = r0 + tfirst_bit(live);
+      live &= live - 1;
+      const int pend = run_first[rr] + run_len[rr];
+      for (int p0 = run_first[rr]; p0 < pend; p0 += TEAM) {
+        const int p = p0 + tl;
+        RawCon rc[4];
+        int mask = 0;
+        if (p < pend && !(NTREE > 1 && far_apart(p))) mask = collide_pair(G, p, rc);
+        if (!tany(mask != 0)) continue;
+        int cnt = 0;
+        for (int c = 0; c < 4; c++) cnt += (mask >> c) & 1;
+        int total;
+        int k = E.ncon + tscan(cnt, total);
+        for (int c = 0; c < 4; c++) {
+          if (!((mask >> c) & 1)) continue;
+          if (k < NCON_MAX) write_contact(W.gcon(k), p, rc[c]);
+          k++;
+        }
+        if (E.ncon + total > NCON_MAX) { E.warn |= WARN_CONTACTFULL; E.ncon = NCON_MAX; }
+        else E.ncon += total;
+      }
+    }
   }
   tsync();
 }
@@ -3653,8 +3669,8 @@ DEV void forward_team(Env& E, const Work& W, bool actuation, real tol) {
     for (int j = dof_treeroot[i] + tl; j <= i; j += TEAM) M.set(tri(i, j), 0);
   if (tl == 0) world_frames(E);
   tsync();
-  if (tl % LANES_PER_GROUP == 0) {
-    for (int t = tl/LANES_PER_GROUP; t < NTREE; t += NGROUPS) {
+  if (tl < NGROUPS) {       // (group g = the lanes g mod NGROUPS; its first lane is lane g)
+    for (int t = tl; t < NTREE; t += NGROUPS) {
       team_range(E, t);
 #ifdef DMC_TREE_PROFILE      // (experiments: the recursions' shares, in the slots of FPROF 0 1 2 3 4)
       long long tq_ = wall_clock64(), tn_;
