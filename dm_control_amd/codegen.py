@@ -548,6 +548,56 @@ def generate_header(m, task=TASK_NONE, ncon_max=None, unroll=None):
   for name, vals in (('tree_body_lo', tb_lo), ('tree_body_hi', tb_hi), ('tree_jnt_lo', tj_lo),
                      ('tree_jnt_hi', tj_hi), ('tree_dof_lo', td_lo), ('tree_dof_hi', td_hi)):
     ti(name, vals or [0])
+  # Segments: maximal runs of consecutive bodies of a tree that form a chain without
+  # branches (a leg, an arm, the spine); a segment hangs from a body of an earlier
+  # one (its "hub") and the recursions of the segments of one level of a tree are
+  # independent -- team builds run them on different lanes.
+  seg_lo, seg_hi, seg_tree, seg_level, seg_hub = [], [], [], [], []
+  seg_of_body = [-1]*m.nbody
+  nchild = [0]*m.nbody
+  for b in range(1, m.nbody):
+    nchild[int(m.body_parentid[b])] += 1
+  for t in range(len(tb_lo)):
+    b = tb_lo[t]
+    while b < tb_hi[t]:
+      start = b
+      parent = int(m.body_parentid[b])
+      b += 1
+      # (the run goes on while a body is the ONLY child of the body before it)
+      while (b < tb_hi[t] and int(m.body_parentid[b]) == b - 1
+             and nchild[b - 1] == 1):
+        b += 1
+      sid = len(seg_lo)
+      for k in range(start, b):
+        seg_of_body[k] = sid
+      seg_lo.append(start); seg_hi.append(b); seg_tree.append(t)
+      seg_hub.append(parent)
+      seg_level.append(0 if parent == 0 else seg_level[seg_of_body[parent]] + 1)
+  nlevel = max(seg_level) + 1 if seg_level else 1
+  per = {}
+  for sid, (t, lv) in enumerate(zip(seg_tree, seg_level)):
+    per.setdefault((t, lv), []).append(sid)
+  maxper = max([len(v) for v in per.values()] or [1])
+  lvl_seg = []
+  for t in range(len(tb_lo)):
+    for lv in range(nlevel):
+      ids = per.get((t, lv), [])
+      lvl_seg += ids + [-1]*(maxper - len(ids))
+  hubs = sorted(set(h for h in seg_hub if h > 0))
+  body_hub = [hubs.index(b) if b in hubs else -1 for b in range(m.nbody)]
+  def _jd(lo, hi, adr, num):
+    ids = [int(adr[b]) + k for b in range(lo, hi) for k in range(int(num[b]))]
+    return (ids[0], ids[-1] + 1) if ids else (0, 0)
+  ci('NSEG', len(seg_lo)); ci('NSEGLEVEL', nlevel); ci('MAXSEGPERLEVEL', maxper)
+  ci('NHUB', len(hubs))
+  ti('seg_body_lo', seg_lo or [0]); ti('seg_body_hi', seg_hi or [0])
+  ti('seg_jnt_lo', [_jd(a, b, m.body_jntadr, m.body_jntnum)[0] for a, b in zip(seg_lo, seg_hi)] or [0])
+  ti('seg_jnt_hi', [_jd(a, b, m.body_jntadr, m.body_jntnum)[1] for a, b in zip(seg_lo, seg_hi)] or [0])
+  ti('seg_dof_lo', [_jd(a, b, m.body_dofadr, m.body_dofnum)[0] for a, b in zip(seg_lo, seg_hi)] or [0])
+  ti('seg_dof_hi', [_jd(a, b, m.body_dofadr, m.body_dofnum)[1] for a, b in zip(seg_lo, seg_hi)] or [0])
+  ti('seg_hub_body', seg_hub or [0])
+  ti('lvl_seg', lvl_seg or [-1])
+  ti('body_hub', body_hub or [-1])
   # ... and of actuators (by the dof an actuator's transmission starts at); -1 / -1:
   # the model's actuators are not grouped by tree (then every tree's lane scans all)
   ta_lo, ta_hi, grouped = [], [], True

@@ -747,7 +747,13 @@ constexpr int TL_CDOFDOT = FIT_G ? TL_GEOM : TL_EXTRA, TL_XAXIS = TL_CDOFDOT + 6
 constexpr int TL_EX1 = FIT_G ? TL_EXTRA : TL_XAXIS + 3*NJX_;
 constexpr int TL_CVEL = FIT_V ? TL_X : TL_EX1, TL_EX2 = FIT_V ? TL_EX1 : TL_EX1 + 6*NBODY;
 constexpr int TL_XANCHOR = FIT_R ? TL_FC : TL_EX2, TL_EX3 = FIT_R ? TL_EX2 : TL_EX2 + 3*NJX_;
-constexpr int TEAM_LDS_WORDS = TEAMED ? TL_EX3 : 1;
+// what the segments of a tree hand to each other at their hubs (the body a segment
+// hangs from): the hub's acceleration, and what the hanging segments add to its
+// force and composite inertia
+constexpr int NHUBX = NHUB > 0 ? NHUB : 1;
+constexpr int HUB_WORDS = 22, HUB_CACC = 0, HUB_CFRC = 6, HUB_CRB = 12;
+constexpr int TL_HUB = TL_EX3;
+constexpr int TEAM_LDS_WORDS = TEAMED ? TL_HUB + HUB_WORDS*NHUBX : 1;
 static_assert(!TEAMED || (long long)TEAM_LDS_WORDS*sizeof(real) <= 160*1024, "team LDS beyond a CU's");
 
 template <bool T> struct WsRowT { typedef GlbRow type; };
@@ -1545,6 +1551,7 @@ DEV void kinematics(Env& E) {
   }
 }
 
+DEV void com_pos_b(Env& E);
 DEV void com_pos(Env& E) {
   DMC_UNROLL
   for (int i = BODY_LO0(E); i < BODY_HI(E); i++)
@@ -1569,6 +1576,10 @@ DEV void com_pos(Env& E) {
       for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] *= inv;
     }
   }
+  com_pos_b(E);
+}
+// the second half of com_pos: inertias and dof axes about the tree's centre of mass
+DEV void com_pos_b(Env& E) {
   DMC_UNROLL
   for (int k = 0; k < 10; k++) E.cinert[k] = 0;
   DMC_UNROLL
@@ -3615,6 +3626,107 @@ DEV void team_range_all(Env&) {}
 #endif
 static_assert(!TEAMED || NTOUCH == 0, "team mode: touch sensors read frames after the solver");
 
+
+// ---------------------------------------------------------------------------
+// Team mode: the recursions of ONE SEGMENT of a tree (a chain of bodies without
+// branches: a leg, the spine, an arm).  The segments of one level of a tree run
+// on different lanes; a segment reads its hub's (the body it hangs from) frames
+// and velocity from the shared arrays, its acceleration from the hub words in LDS,
+// and adds what it passes up (centre-of-mass sums, forces, composite inertia)
+// there.  E's range members name the segment.
+// ---------------------------------------------------------------------------
+DEV void seg_com_init(Env& E) {
+  for (int i = BODY_LO(E); i < BODY_HI(E); i++)
+    for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] = R(body_mass[i])*E.xipos[3*i + k];
+}
+DEV void seg_com_up(Env& E) {
+  for (int i = BODY_HI(E) - 1; i >= BODY_LO(E); i--) {
+    const int pid = body_parentid[i];
+    if (pid == 0) continue;
+    for (int k = 0; k < 3; k++) {
+      if (pid >= BODY_LO(E)) E.subtree_com[3*pid + k] += E.subtree_com[3*i + k];
+      else tatomic_add(E.subtree_com + 3*pid + k, E.subtree_com[3*i + k]);
+    }
+  }
+}
+DEV void seg_com_div(Env& E) {
+  for (int i = BODY_LO(E); i < BODY_HI(E); i++) {
+    if (body_subtreemass[i] < 1e-15) {
+      for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] = E.xipos[3*i + k];
+    } else {
+      const real inv = R(1.0/(body_subtreemass[i] < 1e-15 ? 1.0 : body_subtreemass[i]));
+      for (int k = 0; k < 3; k++) E.subtree_com[3*i + k] *= inv;
+    }
+  }
+}
+// RNE, outward pass: accelerations and the bodies' own forces
+DEV void seg_rne_out(Env& E, real* cacc, real* cfrc, real* hubs) {
+  for (int i = BODY_LO(E); i < BODY_HI(E); i++) {
+    real tmp[6], tmp1[6];
+    const int da = body_dofadr[i], pid = body_parentid[i];
+    for (int k = 0; k < 6; k++) {
+      if (pid >= BODY_LO(E)) cacc[6*i + k] = cacc[6*pid + k];
+      else if (pid == 0) cacc[6*i + k] = (k >= 3 && !(DISABLEFLAGS & DSBL_GRAVITY)) ? -R(gravity[k - 3]) : R(0);
+      else cacc[6*i + k] = hubs[HUB_WORDS*body_hub[pid] + HUB_CACC + k];
+    }
+    for (int j = 0; j < body_dofnum[i]; j++)
+      for (int k = 0; k < 6; k++)
+        cacc[6*i + k] += E.cdof_dot[6*(da + j) + k]*E.qvel[da + j];
+    if (body_hub[i] >= 0)
+      for (int k = 0; k < 6; k++) hubs[HUB_WORDS*body_hub[i] + HUB_CACC + k] = cacc[6*i + k];
+    mul_inert_vec(cfrc + 6*i, E.cinert + 10*i, cacc + 6*i);
+    mul_inert_vec(tmp, E.cinert + 10*i, E.cvel + 6*i);
+    cross_force(tmp1, E.cvel + 6*i, tmp);
+    for (int k = 0; k < 6; k++) cfrc[6*i + k] += tmp1[k];
+  }
+}
+// RNE, inward pass, and the composite inertias (accumulated in place of cinert);
+// then the segment's dofs: qfrc_smooth and composite inertia x axis (see crb_tree)
+DEV void seg_rne_crb_in(Env& E, const Work& W, real* cfrc, real* hubs) {
+  const auto P = W.mat(MAT_A);
+  for (int i = BODY_HI(E) - 1; i >= BODY_LO(E); i--) {
+    const int pid = body_parentid[i], h = body_hub[i];
+    if (h >= 0) {           // what the segments hanging from this body have added
+      for (int k = 0; k < 6; k++) cfrc[6*i + k] += hubs[HUB_WORDS*h + HUB_CFRC + k];
+      for (int k = 0; k < 10; k++) E.cinert[10*i + k] += hubs[HUB_WORDS*h + HUB_CRB + k];
+    }
+    if (pid == 0) continue;
+    if (pid >= BODY_LO(E)) {
+      for (int k = 0; k < 6; k++) cfrc[6*pid + k] += cfrc[6*i + k];
+      for (int k = 0; k < 10; k++) E.cinert[10*pid + k] += E.cinert[10*i + k];
+    } else {
+      real* hp = hubs + HUB_WORDS*body_hub[pid];
+      for (int k = 0; k < 6; k++) tatomic_add(hp + HUB_CFRC + k, cfrc[6*i + k]);
+      for (int k = 0; k < 10; k++) tatomic_add(hp + HUB_CRB + k, E.cinert[10*i + k]);
+    }
+  }
+  for (int i = DOF_LO(E); i < DOF_HI(E); i++) {
+    real buf[6];
+    E.qfrc_smooth[i] = -dot6(E.cdof + 6*i, cfrc + 6*dof_bodyid[i]);
+    mul_inert_vec(buf, E.cinert + 10*dof_bodyid[i], E.cdof + 6*i);
+    for (int k = 0; k < 6; k++) P.set(6*i + k, buf[k]);
+  }
+}
+#ifdef DMC_TEAM
+DEV void team_seg(Env& E, int sid) {
+  E.rb0 = seg_body_lo[sid]; E.rb1 = seg_body_hi[sid];
+  E.rj0 = seg_jnt_lo[sid]; E.rj1 = seg_jnt_hi[sid];
+  E.rd0 = seg_dof_lo[sid]; E.rd1 = seg_dof_hi[sid];
+}
+#else
+DEV void team_seg(Env&, int) {}
+#endif
+// f() for the segments of `level` that this lane runs (group g = lane mod NGROUPS
+// takes the trees g, g + NGROUPS, ...; the lanes of a group split a level's segments)
+template <class F>
+DEV void for_my_segments(Env& E, int level, F&& f) {
+  const int tl = tlane();
+  for (int t = tl % NGROUPS; t < NTREE; t += NGROUPS)
+    for (int q = tl/NGROUPS; q < MAXSEGPERLEVEL; q += LANES_PER_GROUP) {
+      const int sid = lvl_seg[(t*NSEGLEVEL + level)*MAXSEGPERLEVEL + q];
+      if (sid >= 0) { team_seg(E, sid); f(); }
+    }
+}
 // joint limits, a chunk of TEAM limits at a time; rows in the serial order
 DEV void limit_rows_team(Env& E, const Work& W) {
   if (DISABLEFLAGS & (DSBL_LIMIT | DSBL_CONSTRAINT)) return;
@@ -3669,28 +3781,32 @@ DEV void forward_team(Env& E, const Work& W, bool actuation, real tol) {
     for (int j = dof_treeroot[i] + tl; j <= i; j += TEAM) M.set(tri(i, j), 0);
   if (tl == 0) world_frames(E);
   tsync();
-  if (tl < NGROUPS) {       // (group g = the lanes g mod NGROUPS; its first lane is lane g)
-    for (int t = tl; t < NTREE; t += NGROUPS) {
-      team_range(E, t);
-#ifdef DMC_TREE_PROFILE      // (experiments: the recursions' shares, in the slots of FPROF 0 1 2 3 4)
-      long long tq_ = wall_clock64(), tn_;
-#define TPROF(k) do { tn_ = wall_clock64(); E.prof[k] += (real)(tn_ - tq_); tq_ = tn_; } while (0)
-#else
-#define TPROF(k) do {} while (0)
-#endif
-      kinematics(E);
-      TPROF(0);
-      com_pos(E);
-      TPROF(1);
-      com_vel(E);
-      TPROF(2);
-      crb_tree(E, W);
-      TPROF(3);
-      smooth_forces(E, W, actuation);
-      TPROF(4);
-    }
-    team_range_all(E);
+  // the recursions, segment by segment (see seg_*): outward passes level 0, 1, ...;
+  // inward passes from the deepest level; a phase boundary after every level
+  real* const hubs = W.lds + TL_HUB;
+  real cacc[NBODY*6], cfrc[NBODY*6];          // (the entries of this lane's segments)
+  for (int k = tl; k < HUB_WORDS*NHUB; k += TEAM) hubs[k] = 0;
+  for (int lv = 0; lv < NSEGLEVEL; lv++) {
+    for_my_segments(E, lv, [&] { kinematics(E); seg_com_init(E); });
+    tsync();
   }
+  for (int lv = NSEGLEVEL - 1; lv >= 0; lv--) {
+    for_my_segments(E, lv, [&] { seg_com_up(E); });
+    tsync();
+  }
+  for (int lv = 0; lv < NSEGLEVEL; lv++) for_my_segments(E, lv, [&] { seg_com_div(E); });
+  tsync();
+  for (int lv = 0; lv < NSEGLEVEL; lv++) for_my_segments(E, lv, [&] { com_pos_b(E); });
+  tsync();
+  for (int lv = 0; lv < NSEGLEVEL; lv++) {
+    for_my_segments(E, lv, [&] { com_vel(E); seg_rne_out(E, cacc, cfrc, hubs); });
+    tsync();
+  }
+  for (int lv = NSEGLEVEL - 1; lv >= 0; lv--) {
+    for_my_segments(E, lv, [&] { seg_rne_crb_in(E, W, cfrc, hubs); });
+    tsync();
+  }
+  team_range_all(E);
   tsync();
   crb_rows_team(E, W);
   passive_forces(E, tl, NJNT, TEAM, tl, NV, TEAM);
