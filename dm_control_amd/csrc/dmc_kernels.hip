@@ -946,54 +946,6 @@ static __device__ __noinline__ int tile_factor_rows(real* T, int n) {     // (on
   tsync();
   return nbad;
 }
-// One-dof rows (joint limits) that enter or leave the active set change ONE diagonal
-// entry of a tree's block: instead of factoring the block again its factor takes a
-// rank-one update (w > 0) or downdate (w < 0), rows in registers as above, one
-// column per step from the entry's dof on (Givens-like recurrences; the column's
-// pivot and the carried vector's entry travel by lane broadcast).  A downdate
-// that would cancel most of a pivot is refused (returns false: the caller factors
-// the block again from H).
-#ifdef DMC_REAL_IS_DOUBLE
-#define DMC_RANK1_MIN 1e-6
-#else
-#define DMC_RANK1_MIN 1e-2f
-#endif
-static __device__ __noinline__ bool tile_rank1(real* T, const real* p1, int n1, int s, int n) {
-  const int i = tlane();
-  real r[TB];
-  _Pragma("unroll")
-  for (int k = 0; k < TB; k++) r[k] = (i < n && k <= i) ? T[i*TSTR + k] : R(0);
-  bool ok = true;
-  for (int f = 0; f < n1; f++) {
-    const int d = (int)p1[2*f] - s;
-    if (d < 0 || d >= n) continue;
-    const real w = p1[2*f + 1];
-    const real sg = w < 0 ? R(-1) : R(1);
-    real wv = i == d ? sqrt(fabs(w)) : R(0);
-    _Pragma("unroll")
-    for (int k = 0; k < TB; k++) {
-      if (k >= d && k < n) {
-        const real pk = tget(r[k], k);            // 1 / L[k][k]
-        const real vk = tget(wv, k);
-        const real lkk = R(1)/pk;
-        real r2 = lkk*lkk + sg*vk*vk;
-        if (!(r2 >= R(DMC_RANK1_MIN)*lkk*lkk)) { ok = false; r2 = R(DMC_RANK1_MIN)*lkk*lkk; }
-        const real rr = sqrt(r2);
-        const real c = rr*pk, sn = vk*pk;
-        if (i == k) r[k] = R(1)/rr;
-        else if (i > k) {
-          const real l = (r[k] + sg*sn*wv)/c;
-          wv = c*wv - sn*l;
-          r[k] = l;
-        }
-      }
-    }
-  }
-  _Pragma("unroll")
-  for (int k = 0; k < TB; k++) if (i < n && k <= i) T[i*TSTR + k] = r[k];
-  tsync();
-  return ok;
-}
 DEV int tile_factor(real* T, int n) {
   if (TEAM == TB) return tile_factor_rows(T, n);
   const int tl = tlane();
@@ -1162,12 +1114,10 @@ DEV void flip_apply_row(real* T, const real* seg, real w, int c0, int c1, int s)
   }
 }
 // the listed changes that touch the tile [s, e]; four row segments in flight
-DEV bool team_tile_flips_listed(real* T, const Work& W, const FlipList& L, int s, int e,
-                                bool skip_one_dof = false) {
+DEV bool team_tile_flips_listed(real* T, const Work& W, const FlipList& L, int s, int e) {
   const int tl = tlane();
   real* seg = W.lds + TL_ROW;
   bool any = false;
-  if (!skip_one_dof)
   for (int f = tl; f < L.n1; f += TEAM) {          // the one-dof rows: one diagonal entry each
     const int d = (int)L.p1[2*f];
     if (d >= s && d <= e) { tatomic_add(T + (d - s)*TSTR + (d - s), L.p1[2*f + 1]); any = true; }
@@ -1318,43 +1268,25 @@ DEV void tile_forward(const real* T, real* x, int n);
 template <class Mat>
 DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hlo,
                     unsigned coupled, real damping_h, bool flips, const FlipList& L,
-                    bool first, int nefc, const Mat& H, real* xfwd = nullptr, int* nfact = nullptr) {
+                    bool first, int nefc, const Mat& H, real* xfwd = nullptr) {
   real* T = W.lds + TL_TILE;
   const int tl = tlane();
   int nbad = 0;
   if (flips && coupled) team_cross_flips(H, W, nefc, hlo, first);
   for (int t = 0; t < NDTREE; t++) {
     const int s = dtree_lo[t], e = dtree_hi[t], n = e - s + 1;
-    bool one_dof_in_h = false;
     if (flips && !first && !coupled && L.n >= 0 && xfwd) {
       // a block that no listed change touches keeps its factor: only the
       // right-hand side passes through it
-      bool touched1 = false, touchedn = false;
-      for (int f = tl; f < L.n1; f += TEAM) { const int d = (int)L.p1[2*f]; touched1 |= d >= s && d <= e; }
-      for (int f = tl; f < L.n; f += TEAM) touchedn |= (int)L.p[4*f + 2] >= s && (int)L.p[4*f + 1] <= e;
-      touched1 = tany(touched1); touchedn = tany(touchedn);
-      if (!touched1 && !touchedn) {
+      bool touched = false;
+      for (int f = tl; f < L.n1; f += TEAM) { const int d = (int)L.p1[2*f]; touched |= d >= s && d <= e; }
+      for (int f = tl; f < L.n; f += TEAM) touched |= (int)L.p[4*f + 2] >= s && (int)L.p[4*f + 1] <= e;
+      if (!tany(touched)) {
         tile_load(T, dst, s, n);
         tile_forward(T, xfwd + s, n);
         continue;
       }
-      if (!touchedn && TEAM == TB) {
-        // only joint-limit rows changed sides in this block: H takes the diagonal
-        // entries, the factor a rank-one change per row (tile_rank1)
-        for (int f = tl; f < L.n1; f += TEAM) {
-          const int d = (int)L.p1[2*f];
-          if (d >= s && d <= e) H.set(tri(d, d), H.get(tri(d, d)) + L.p1[2*f + 1]);
-        }
-        tile_load(T, dst, s, n);
-        if (tile_rank1(T, L.p1, L.n1, s, n)) {
-          tile_forward(T, xfwd + s, n);
-          tile_store(dst, T, s, n);
-          continue;
-        }
-        one_dof_in_h = true;            // (refused: factor the block again from H, which has the entries)
-      }
     }
-    if (nfact) *nfact += 1;          // (experiments: tiles that were factored again)
     const bool coupled_here = flips && ((coupled >> t) & 1u);
     // (a chain -- this tree coupled to one that is itself coupled further left -- is
     // left to the rows-in-HBM path: the staged solve assumes block-diagonal earlier factors)
@@ -1368,9 +1300,9 @@ DEV int team_factor(const Work& W, const Mat& dst, const Mat& src, const int* hl
       tsync();
     }
     if (flips) {
-      const bool changed = L.n >= 0 ? team_tile_flips_listed(T, W, L, s, e, one_dof_in_h)
+      const bool changed = L.n >= 0 ? team_tile_flips_listed(T, W, L, s, e)
                                     : team_tile_flips_scanned(T, W, nefc, s, e);
-      if ((changed && !one_dof_in_h) || first) tile_store(H, T, s, n);
+      if (changed || first) tile_store(H, T, s, n);
       if (coupled_here) {
         if (staged) team_coupled_take(T, dst, hlo, s, e);
         else {                       // (a chain, or fewer lanes than rows: the rows are walked in HBM)
@@ -3445,13 +3377,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     if (iter > 0 && (converged || scale*improvement < tol || scale*sqrt(gn) < tol)) break;
     if (iter >= ITERATIONS) break;
     tsync();
-#ifdef DMC_TILE_COUNT
-    { int nf = 0;
-      team_factor(W, F, iter == 0 ? M : H, henv, coupled, R(0), true, flips, iter == 0, nefc, H, search, &nf);
-      E.prof[7] += (real)nf; }
-#else
     team_factor(W, F, iter == 0 ? M : H, henv, coupled, R(0), true, flips, iter == 0, nefc, H, search);
-#endif
     SPROF(1);
     team_solve(W, search, F, henv, coupled, true);
     SPROF(2);
@@ -3513,9 +3439,7 @@ DEV void solve_newton_team(Env& E, const Work& W, real tol, bool start_smooth) {
     const real dtol = DMC_F32_RULES ? fmax(gtol, R(1e-5)*fabs(p0.d0)) : gtol;
     for (int it = 0; it < DMC_LS_MAXIT; it++) {
       if (!(DMC_F32_RULES && it == 0)) {
-#ifndef DMC_TILE_COUNT
         SCOUNT(7);
-#endif
         real dcost = 0, d0 = 0, d1 = 0;
         for (int r = tl; r < nefc; r += TEAM) {
           const auto rec = W.grow(r);

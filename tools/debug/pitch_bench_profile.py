@@ -5,7 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 WHAT = sys.argv[1]
-os.environ['DMC_EXTRA_FLAGS'] = {'solver': '-DDMC_SOLVER_PROFILE=1', 'tiles': '-DDMC_SOLVER_PROFILE=1 -DDMC_TILE_COUNT=1', 'stage': '-DDMC_STEP_PROFILE=1',
+os.environ['DMC_EXTRA_FLAGS'] = {'solver': '-DDMC_SOLVER_PROFILE=1', 'stage': '-DDMC_STEP_PROFILE=1',
                                  'tree': '-DDMC_STEP_PROFILE=1 -DDMC_TREE_PROFILE=1'}[WHAT]
 import numpy as np
 from dm_control_amd.locomotion import soccer
@@ -23,13 +23,13 @@ env = soccer.load(2, random_state=1, environment_kwargs={'batch_size': B})
 env.reset()
 rs = np.random.RandomState(0)
 hb = env.physics.batch
-if WHAT not in ('solver', 'tiles'):
+if WHAT != 'solver':
   hb.set_aux_outputs(True)
 for t in range(int(sys.argv[2]) if len(sys.argv) > 2 else 12):
   env.step([rs.uniform(-1, 1, (B, 56)) for _ in range(4)])
 hb.sync()
 st = hb.read(W.FIELD_STATS)
-if WHAT in ('solver', 'tiles'):
+if WHAT == 'solver':
   obs = np.asarray(hb.read(W.FIELD_OBS)).reshape(B, -1)[:, :8].T.astype(np.float64)
   names = ['pass A + gradient', 'Hessian tiles + factor', 'solve', 'M*search, q1 q2', 'pass B (Jv)', 'line search']
   tot = obs[:6].sum(axis=0)/100.0
@@ -37,8 +37,6 @@ if WHAT in ('solver', 'tiles'):
     print('  %-24s mean %9.1f us  max %9.1f us' % (names[k], obs[k].mean()/100.0, obs[k].max()/100.0))
   print('  solver total per pitch: mean %.0f us p90 %.0f max %.0f' % (tot.mean(), np.percentile(tot, 90), tot.max()))
   print('  iterations with a step: mean %.1f max %d' % (obs[6].mean(), obs[6].max()))
-  if WHAT == 'tiles':
-    print('  tiles factored again (of %d per iteration): mean %.1f per control step = %.2f per iteration' % (5, obs[7].mean(), obs[7].mean()/max(obs[6].mean(), 1)))
   worst = int(np.argmax(tot))
   print('  slowest pitch %d: ncon %d nefc %d; phases %s' % (worst, st[0][worst], st[1][worst], np.round(obs[:6, worst]/100.0)))
 else:
