@@ -375,10 +375,12 @@ def load(team_size, time_limit=45., random_state=None, disable_walker_contacts=F
                     disable_walker_contacts=disable_walker_contacts,
                     ball=scene.REGULATION_BALL, goal_size=MINI_FOOTBALL_GOAL_SIZE)
   phys_kw, _, env_kw = common.split_kwargs(environment_kwargs)
-  # contact capacity: 16 per player (the reference allocates 200 per player,
-  # task.py:105-108; a standing or fallen humanoid touches the pitch in <= 10
-  # places); beyond it the step raises mjWARN_CONTACTFULL like the reference
-  phys_kw.setdefault('ncon_max', 16*num_walkers)
+  # contact capacity: 40 per player (the reference allocates 200 per player,
+  # task.py:105-108).  Fallen humanoids with self-collisions on reached 27 contacts
+  # per player in a 600-step soak of 512 pitches under random actions
+  # (tools/debug/soccer_soak.py; 16 per player raised mjWARN_CONTACTFULL in 71 of
+  # them); beyond the capacity the step raises mjWARN_CONTACTFULL like the reference
+  phys_kw.setdefault('ncon_max', 40*num_walkers)
   physics = Physics.from_xml_string(xml, **phys_kw)
   task = Task(team_size, geometry, random=random_state,
               terminate_on_goal=terminate_on_goal)

@@ -17,7 +17,7 @@ if '--build-only' in sys.argv:
   from dm_control_amd.mjcf import compiler
   geometry = soccer.PitchGeometry(soccer.area_to_size(soccer.MINI_FOOTBALL_MIN_AREA_PER_HUMANOID*4), soccer.MINI_FOOTBALL_GOAL_SIZE)
   xml = scene.build(4, with_ball=True, pitch_size=geometry.size, ball=scene.REGULATION_BALL, goal_size=soccer.MINI_FOOTBALL_GOAL_SIZE)
-  print(os.path.basename(build.build_model(compiler.from_xml_string(xml), 0, 'f32', ncon_max=64, mode='team')))
+  print(os.path.basename(build.build_model(compiler.from_xml_string(xml), 0, 'f32', ncon_max=160, mode='team')))
   sys.exit(0)
 env = soccer.load(2, random_state=1, environment_kwargs={'batch_size': B})
 env.reset()
