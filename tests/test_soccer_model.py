@@ -470,3 +470,60 @@ def test_oracle_at_its_row_capacity_flags_and_stays_in_bounds():
     d.physics_step()
     top = max(top, d.nefc)
   assert top == 70 and d.warning[2] > 0 and np.isfinite(d.qpos).all()
+
+
+def test_tables_of_the_team_build():
+  """What codegen adds for scenes of several trees (csrc/dmc_kernels.hip, team mode):
+  the pair list grouped into runs that one bounding test can skip, and every tree
+  cut into chains without branches ("segments") on levels."""
+  import re
+  from dm_control_amd import codegen
+  m = _pitch_model(False)
+  text = codegen.generate_header(m, ncon_max=64)
+  def table(name):
+    return [int(x) for x in re.search(r'%s\[\] = \{([^}]*)\}' % name, text).group(1).split(',')]
+  def const(name):
+    return int(re.search(r'constexpr int %s = (-?\d+)' % name, text).group(1))
+  # segments: a partition of the bodies into runs of consecutive bodies, each a chain
+  lo, hi, hub = table('seg_body_lo'), table('seg_body_hi'), table('seg_hub_body')
+  assert const('NSEG') == len(lo) == 45 and const('NSEGLEVEL') == 4      # 11 per walker + the ball
+  covered = [b for a, e in zip(lo, hi) for b in range(a, e)]
+  assert covered == list(range(1, m.nbody))
+  parent = [int(p) for p in m.body_parentid]
+  level = {}
+  for sid, (a, e, h) in enumerate(zip(lo, hi, hub)):
+    assert parent[a] == h                                   # the segment hangs from its hub
+    assert all(parent[b] == b - 1 for b in range(a + 1, e))   # a chain inside
+    seg_of_hub = next((k for k in range(sid) if lo[k] <= h < hi[k]), None)
+    level[sid] = 0 if h == 0 else level[seg_of_hub] + 1
+  per_level = table('lvl_seg')
+  width = const('MAXSEGPERLEVEL')
+  ntree = len(table('tree_body_lo'))
+  seen = set()
+  for t in range(ntree):
+    for lv in range(4):
+      for sid in per_level[(t*4 + lv)*width:(t*4 + lv + 1)*width]:
+        if sid >= 0:
+          assert level[sid] == lv and table('tree_body_lo')[t] <= lo[sid] < table('tree_body_hi')[t]
+          seen.add(sid)
+  assert seen == set(range(45))
+  hubs = sorted(set(h for h in hub if h > 0))
+  assert const('NHUB') == len(hubs) and [table('body_hub')[h] for h in hubs] == list(range(len(hubs)))
+  # pair runs: the same pairs as MuJoCo's filters leave, every keyed run homogeneous
+  pairs = codegen.collision_pairs(m)
+  assert len(pairs) == 18883 and len(set(pairs)) == len(pairs)
+  first, length, keyed = table('run_first'), table('run_len'), table('run_keyed')
+  assert sum(length) == len(pairs) and first[0] == 0
+  assert all(first[k + 1] == first[k] + length[k] for k in range(len(first) - 1))
+  t1, t2, wg = table('pair_tree1'), table('pair_tree2'), table('pair_wgeom')
+  for f, n, k in zip(first, length, keyed):
+    kinds = set((min(t1[p], t2[p]), max(t1[p], t2[p]), wg[p]) for p in range(f, f + n))
+    if k:
+      assert len(kinds) == 1
+      a, b, g = next(iter(kinds))
+      assert (a >= 0 and b >= 0 and a != b and g < 0) or (a < 0 <= b and g >= 0)
+    else:
+      assert all(a == b or (a < 0 and b < 0) for a, b, _ in kinds)
+  # 25 world geoms x 5 trees + 10 tree pairs can be skipped; the pairs inside the trees are one run
+  assert sum(keyed) == 135 and len(first) == 136
+  assert max(n for n, k in zip(length, keyed) if k) == 1849 and max(length) == 3292
