@@ -600,7 +600,10 @@ def main(argv=None):
         'roofline': {
             # the contract's figure (north_star: achieved HBM GB/s vs 8 TB/s);
             # what actually limits the kernel is VALU issue, see `valu`
-            'bound': 'hbm', 'limited_by': 'valu-issue',
+            'bound': 'hbm',
+            'limited_by': ('dependent-memory-latency (one wavefront per env: tiles and tables '
+                           'travel through HBM / LDS on a serial chain)'
+                           if 'team mode' in physics.kernel_shape else 'valu-issue'),
             'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved/HBM_PEAK_GBS,
             'traffic': counters.get('traffic_bytes_per_launch'),
