@@ -912,8 +912,23 @@ DEV void tile_load(real* T, const Mat& A, int s, int n) {
 template <class Mat>
 DEV void tile_store(const Mat& A, const real* T, int s, int n) {
   const int tl = tlane();
-  for (int ii = 0; ii < n; ii++)
-    for (int k = tl; k <= ii; k += TEAM) A.set(tri(s + ii, s + k), T[ii*TSTR + k]);
+  for (int i0 = 0; i0 < n; i0 += 16) {          // sixteen rows' LDS reads in flight
+    real v[16][KPL];
+    _Pragma("unroll")
+    for (int u = 0; u < 16; u++)
+      _Pragma("unroll")
+      for (int m = 0; m < KPL; m++) {
+        const int ii = i0 + u, k = tl + m*TEAM;
+        v[u][m] = (ii < n && k <= ii) ? T[ii*TSTR + k] : R(0);
+      }
+    _Pragma("unroll")
+    for (int u = 0; u < 16; u++)
+      _Pragma("unroll")
+      for (int m = 0; m < KPL; m++) {
+        const int ii = i0 + u, k = tl + m*TEAM;
+        if (ii < n && k <= ii) A.set(tri(s + ii, s + k), v[u][m]);
+      }
+  }
   tsync();
 }
 // in place T = L L^T (lower part), the diagonal keeps the inverse pivots.  One
